@@ -1,0 +1,128 @@
+/*
+ * chaindp.h -- C ABI of the MI355X chaining-DP library (libchaindp_hip.so).
+ *
+ * This is the in-process entry to the device half of minimap2's anchor chaining
+ * as the reference fork splits it:
+ *
+ *   reference chain.c:218-327  mm_chain_dp_fpga(max_dist_x, max_dist_y, bw, max_skip,
+ *                              min_sc, is_cdna, n_segs, n, a, &new_i) -> new_seed[]
+ *
+ * Each chaindp_* call below processes a BATCH of reads (CSR layout) instead of one
+ * read per call; per read the results are bit-identical to that function:
+ * f[]/p[]/v[] are the arrays of chain.c:246-284, new_seed[] the compaction of
+ * chain.c:286-317.  Plain pointers and sizes only; no torch or HIP types.
+ * The packet-level driver ABI of the reference (fpga.h) is in chaindp_fpga.h.
+ *
+ * Types mirror the reference byte for byte:
+ *   chaindp_anchor_t == mm128_t            (minimap.h:48)
+ *   chaindp_seed_t   == struct new_seed    (minimap.h:51-55, 24 bytes)
+ * Anchors of a read must be sorted ascending by x (map.c:233).
+ */
+#ifndef CHAINDP_H
+#define CHAINDP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint64_t x, y; } chaindp_anchor_t;
+typedef struct { chaindp_anchor_t seed; int32_t p, f; } chaindp_seed_t;
+
+/* Arguments of mm_chain_dp_fpga in its order (chain.c:218); n_segs may be overridden
+ * per read by the n_segs_per_read arrays below (collect_task_t::n_segs, fpga_chaindp.h:53). */
+typedef struct {
+	int32_t max_dist_x;   /* max_chain_gap_ref, map.c:361-366 */
+	int32_t max_dist_y;   /* max_chain_gap_qry, map.c:358-360 */
+	int32_t bw;
+	int32_t max_skip;
+	int32_t min_sc;
+	int32_t is_cdna;
+	int32_t n_segs;
+} chaindp_params_t;
+
+typedef struct chaindp_ctx chaindp_ctx_t;
+
+#define CHAINDP_OK            0
+#define CHAINDP_ERR_ARG      (-1)   /* bad argument (NULL pointer, negative size, negative gap/bw) */
+#define CHAINDP_ERR_CAPACITY (-2)   /* batch larger than the context was created for */
+#define CHAINDP_ERR_HIP      (-3)   /* a HIP runtime call failed; see chaindp_last_error() */
+#define CHAINDP_ERR_NODEVICE (-4)   /* no usable GPU */
+
+/* Number of HIP devices visible to the process (0 when there is none). */
+int chaindp_device_count(void);
+
+/* One context per (host thread, GPU): owns a stream, device buffers for up to
+ * max_anchors anchors / max_reads reads, and pinned host staging of the same size.
+ * Returns NULL on failure (no device, out of memory). */
+chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_t max_reads);
+void chaindp_destroy(chaindp_ctx_t *ctx);
+const char *chaindp_last_error(const chaindp_ctx_t *ctx);   /* ctx may be NULL: last create() error */
+
+/* ---- host-buffer path (what the packet shim uses) -------------------------------------
+ * off[n_reads+1]: CSR offsets into a[] (off[0] == 0); n_segs_per_read may be NULL.
+ * chaindp_chain_batch = upload + run + download, synchronous.  v may be NULL. */
+int chaindp_chain_batch(chaindp_ctx_t *ctx, const chaindp_params_t *par, int64_t n_reads, const int64_t *off,
+                        const chaindp_anchor_t *a, const int32_t *n_segs_per_read,
+                        int32_t *f, int32_t *p, int32_t *v);
+
+/* The same in stages, so that a caller can keep a batch resident in HBM and time or
+ * repeat the device stage alone.  upload/download are synchronous; run is asynchronous
+ * on the context's stream until chaindp_sync(). */
+int chaindp_upload(chaindp_ctx_t *ctx, int64_t n_reads, const int64_t *off, const chaindp_anchor_t *a,
+                   const int32_t *n_segs_per_read);
+int chaindp_run(chaindp_ctx_t *ctx, const chaindp_params_t *par);
+int chaindp_sync(chaindp_ctx_t *ctx);
+int chaindp_download(chaindp_ctx_t *ctx, int32_t *f, int32_t *p, int32_t *v);
+
+/* Compaction of the resident f/p/v into the wire format of the reference's result
+ * packets (chain.c:286-317): seeds_off[n_reads+1] receives the CSR offsets of each
+ * read's new_seed[] (seeds_off[r+1]-seeds_off[r] == new_i of read r), seeds[] the
+ * records; seeds must have room for the batch's anchor count.  Requires a completed
+ * chaindp_run on the same batch. */
+int chaindp_compact(chaindp_ctx_t *ctx, const chaindp_params_t *par, int64_t *seeds_off, chaindp_seed_t *seeds);
+
+/* Scatter/gather variants used by the packet shim, whose reads sit in separate (pinned) packet
+ * buffers: upload from one host pointer per read; run the compaction and return only the offsets;
+ * then copy each read's new_seed[] straight to its place in a result packet (asynchronous on the
+ * context's stream: call chaindp_sync() before touching dst). */
+int chaindp_upload_gather(chaindp_ctx_t *ctx, int64_t n_reads, const int64_t *off,
+                          const chaindp_anchor_t *const *read_anchors, const int32_t *n_segs_per_read);
+int chaindp_compact_offsets(chaindp_ctx_t *ctx, const chaindp_params_t *par, int64_t *seeds_off);
+int chaindp_download_seeds(chaindp_ctx_t *ctx, int64_t first_seed, int64_t n_seeds, chaindp_seed_t *dst);
+
+/* Pinned host memory (hipHostMalloc) for callers that want DMA-able staging buffers. */
+void *chaindp_host_alloc(size_t bytes);
+void chaindp_host_free(void *p);
+
+/* ---- device-pointer path (inputs and outputs already in HBM) ---------------------------
+ * All pointers are device addresses on ctx's GPU; stream is a hipStream_t passed as
+ * void* (NULL = the context's own stream).  d_off int64[n_reads+1], d_a anchors,
+ * d_n_segs int32[n_reads] or NULL, d_f/d_p/d_v int32[total_anchors] (d_v may NOT be NULL
+ * here: the recurrence needs it as storage).  total_anchors must equal off[n_reads].
+ * Asynchronous. */
+int chaindp_run_device(chaindp_ctx_t *ctx, const chaindp_params_t *par, int64_t n_reads, int64_t total_anchors,
+                       const void *d_off, const void *d_a, const void *d_n_segs,
+                       void *d_f, void *d_p, void *d_v, void *stream);
+
+/* ---- measurement ----------------------------------------------------------------------
+ * With profiling on, every run brackets each kernel with HIP events on the stream it is
+ * launched on; the accumulated device times are read back (after chaindp_sync) here.
+ * ms[0] = prepass kernel, ms[1] = chain DP kernel, ms[2] = compaction kernels;
+ * launches[i] = number of launches accumulated.  reset != 0 clears the accumulators. */
+int chaindp_set_profiling(chaindp_ctx_t *ctx, int on);
+int chaindp_get_kernel_ms(chaindp_ctx_t *ctx, double ms[3], int64_t launches[3], int reset);
+
+/* Work decomposition of the last run: st[0] = units (independent DP problems, >= 2 anchors),
+ * st[1] = singleton anchors resolved in the prepass, st[2] = anchors, st[3] = reads. */
+int chaindp_get_stats(chaindp_ctx_t *ctx, int64_t st[4]);
+
+/* Kernel tuning knob, mainly for tests: LDS ring capacity in anchors (128, 256 or 512). */
+int chaindp_set_ring(chaindp_ctx_t *ctx, int ring);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

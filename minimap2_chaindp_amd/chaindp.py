@@ -1,0 +1,184 @@
+"""Python front end of the C ABI in include/chaindp.h (libchaindp_hip.so).
+
+Thin by design: numpy arrays in, numpy arrays out, every call goes through the C ABI to the HIP
+kernels.  There is NO CPU implementation behind this module: a missing library or a missing GPU
+raises.  Per read the results equal the reference's mm_chain_dp_fpga (chain.c:218-327).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .params import ChainParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libchaindp_hip.so")
+
+SEED_DTYPE = np.dtype([("x", "<u8"), ("y", "<u8"), ("p", "<i4"), ("f", "<i4")])  # struct new_seed (minimap.h:51-55)
+
+# every symbol include/chaindp.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = (
+    "chaindp_device_count", "chaindp_create", "chaindp_destroy", "chaindp_last_error", "chaindp_chain_batch",
+    "chaindp_upload", "chaindp_run", "chaindp_sync", "chaindp_download", "chaindp_compact",
+    "chaindp_upload_gather", "chaindp_compact_offsets", "chaindp_download_seeds", "chaindp_host_alloc",
+    "chaindp_host_free", "chaindp_run_device", "chaindp_set_profiling", "chaindp_get_kernel_ms",
+    "chaindp_get_stats", "chaindp_set_ring",
+)
+
+
+class ChainDPError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ChainDPError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                               "(make -C minimap2_chaindp_amd/csrc); there is no fallback path")
+        L = C.CDLL(LIB_PATH)
+        P = C.POINTER(ChainParams)
+        vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+        L.chaindp_device_count.restype = i32
+        L.chaindp_create.restype = vp
+        L.chaindp_create.argtypes = [i32, i64, i64]
+        L.chaindp_destroy.argtypes = [vp]
+        L.chaindp_last_error.restype = C.c_char_p
+        L.chaindp_last_error.argtypes = [vp]
+        L.chaindp_chain_batch.argtypes = [vp, P, i64, vp, vp, vp, vp, vp, vp]
+        L.chaindp_upload.argtypes = [vp, i64, vp, vp, vp]
+        L.chaindp_run.argtypes = [vp, P]
+        L.chaindp_sync.argtypes = [vp]
+        L.chaindp_download.argtypes = [vp, vp, vp, vp]
+        L.chaindp_compact.argtypes = [vp, P, vp, vp]
+        L.chaindp_upload_gather.argtypes = [vp, i64, vp, vp, vp]
+        L.chaindp_compact_offsets.argtypes = [vp, P, vp]
+        L.chaindp_download_seeds.argtypes = [vp, i64, i64, vp]
+        L.chaindp_host_alloc.restype = vp
+        L.chaindp_host_alloc.argtypes = [C.c_size_t]
+        L.chaindp_host_free.argtypes = [vp]
+        L.chaindp_run_device.argtypes = [vp, P, i64, i64, vp, vp, vp, vp, vp, vp, vp]
+        L.chaindp_set_profiling.argtypes = [vp, i32]
+        L.chaindp_get_kernel_ms.argtypes = [vp, vp, vp, i32]
+        L.chaindp_get_stats.argtypes = [vp, vp]
+        L.chaindp_set_ring.argtypes = [vp, i32]
+        _lib = L
+    return _lib
+
+
+def device_count():
+    return lib().chaindp_device_count()
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Device:
+    """One chaining context on one GPU (chaindp_ctx_t)."""
+
+    def __init__(self, device=0, max_anchors=1 << 24, max_reads=1 << 20, ring=None):
+        self._lib = lib()
+        if self._lib.chaindp_device_count() <= 0:
+            raise ChainDPError("no HIP device visible: the chaining DP runs only on the GPU (no CPU fallback)")
+        self._ctx = self._lib.chaindp_create(device, max_anchors, max_reads)
+        if not self._ctx:
+            raise ChainDPError(self._lib.chaindp_last_error(None).decode())
+        self.device = device
+        self.max_anchors, self.max_reads = max_anchors, max_reads
+        self._n_reads = self._total = 0
+        if ring is not None:
+            self._check(self._lib.chaindp_set_ring(self._ctx, ring))
+
+    # -- lifecycle
+    def close(self):
+        if self._ctx:
+            self._lib.chaindp_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ChainDPError(f"chaindp error {rc}: {self._lib.chaindp_last_error(self._ctx).decode()}")
+
+    @staticmethod
+    def _prep(off, anchors, n_segs):
+        off = np.ascontiguousarray(off, np.int64)
+        anchors = np.ascontiguousarray(anchors, np.uint64).reshape(-1, 2)
+        if len(off) < 1 or off[0] != 0 or int(off[-1]) != anchors.shape[0]:
+            raise ValueError("off must start at 0 and end at the number of anchors")
+        ns = None if n_segs is None else np.ascontiguousarray(n_segs, np.int32)
+        if ns is not None and len(ns) != len(off) - 1:
+            raise ValueError("n_segs must have one entry per read")
+        return off, anchors, ns
+
+    # -- host-buffer path
+    def chain_batch(self, par, off, anchors, n_segs=None, want_v=True):
+        """f, p, v (int32[total]) of every read of the batch; mm_chain_dp_fpga's arrays (chain.c:246-284)."""
+        off, anchors, ns = self._prep(off, anchors, n_segs)
+        tot = anchors.shape[0]
+        f, p = np.empty(tot, np.int32), np.empty(tot, np.int32)
+        v = np.empty(tot, np.int32) if want_v else None
+        self._check(self._lib.chaindp_chain_batch(self._ctx, C.byref(par), len(off) - 1, _ptr(off), _ptr(anchors), _ptr(ns),
+                                                  _ptr(f), _ptr(p), _ptr(v)))
+        self._n_reads, self._total = len(off) - 1, tot
+        return f, p, v
+
+    def upload(self, off, anchors, n_segs=None):
+        off, anchors, ns = self._prep(off, anchors, n_segs)
+        self._check(self._lib.chaindp_upload(self._ctx, len(off) - 1, _ptr(off), _ptr(anchors), _ptr(ns)))
+        self._n_reads, self._total = len(off) - 1, anchors.shape[0]
+
+    def run(self, par):
+        self._check(self._lib.chaindp_run(self._ctx, C.byref(par)))
+
+    def sync(self):
+        self._check(self._lib.chaindp_sync(self._ctx))
+
+    def download(self, want_v=True):
+        f, p = np.empty(self._total, np.int32), np.empty(self._total, np.int32)
+        v = np.empty(self._total, np.int32) if want_v else None
+        self._check(self._lib.chaindp_download(self._ctx, _ptr(f), _ptr(p), _ptr(v)))
+        return f, p, v
+
+    def compact(self, par):
+        """new_seed[] of every read (chain.c:286-317): (seeds_off int64[n_reads+1], seeds SEED_DTYPE[...])."""
+        soff = np.zeros(self._n_reads + 1, np.int64)
+        seeds = np.zeros(max(self._total, 1), SEED_DTYPE)
+        self._check(self._lib.chaindp_compact(self._ctx, C.byref(par), _ptr(soff), _ptr(seeds)))
+        return soff, seeds[:int(soff[-1])]
+
+    # -- device-pointer path (torch tensors or any other HBM allocation)
+    def run_device(self, par, n_reads, total, d_off, d_a, d_n_segs, d_f, d_p, d_v, stream=0):
+        self._check(self._lib.chaindp_run_device(self._ctx, C.byref(par), n_reads, total, d_off, d_a, d_n_segs or None,
+                                                 d_f, d_p, d_v, stream or None))
+
+    # -- measurement
+    def set_profiling(self, on=True):
+        self._check(self._lib.chaindp_set_profiling(self._ctx, int(bool(on))))
+
+    def kernel_ms(self, reset=False):
+        """Accumulated HIP-event device time per kernel: dict name -> (ms, launches)."""
+        ms = (C.c_double * 3)()
+        n = (C.c_int64 * 3)()
+        self._check(self._lib.chaindp_get_kernel_ms(self._ctx, ms, n, int(reset)))
+        return {k: (ms[i], n[i]) for i, k in enumerate(("prepass", "chain_dp", "compact"))}
+
+    def stats(self):
+        st = (C.c_int64 * 4)()
+        self._check(self._lib.chaindp_get_stats(self._ctx, st))
+        return dict(units=st[0], singletons=st[1], anchors=st[2], reads=st[3])

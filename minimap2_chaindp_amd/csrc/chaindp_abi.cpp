@@ -1,0 +1,382 @@
+// chaindp_abi.cpp -- host side of the C ABI declared in include/chaindp.h.
+// Owns the per-GPU context (stream, HBM buffers, scratch), stages batches and launches the kernels
+// of chaindp_kernels.hip / chaindp_compact.hip.  No CPU implementation of the DP exists in this
+// library: without a GPU every entry point fails with CHAINDP_ERR_NODEVICE.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/chaindp.h"
+#include "chaindp_kernels.h"
+
+using chaindp::Params;
+using chaindp::Unit;
+
+static thread_local std::string g_create_error;
+
+struct EventSet { hipEvent_t e[3]; int n; int slot0; };  // e[0..n): consecutive kernel boundaries; slot0 = first ms[] index
+
+struct chaindp_ctx {
+	int device = -1;
+	hipStream_t stream = nullptr;
+	int64_t cap_anchors = 0, cap_reads = 0;
+	int ring = 256;
+	// resident batch
+	int64_t n_reads = 0, total = 0, n_seeds = 0;
+	bool has_n_segs = false, ran = false;
+	int64_t *d_off = nullptr;
+	void *d_a = nullptr;
+	int32_t *d_n_segs = nullptr;
+	int32_t *d_f = nullptr, *d_p = nullptr, *d_v = nullptr;
+	// scratch
+	int32_t *d_tg = nullptr;
+	float *d_avgq = nullptr;
+	Unit *d_units = nullptr;
+	unsigned long long *d_counters = nullptr;
+	// compaction (allocated on first use)
+	int32_t *d_first_child = nullptr, *d_id = nullptr;
+	int64_t *d_seeds_off = nullptr;
+	void *d_seeds = nullptr;
+	// profiling
+	bool prof = false;
+	std::vector<EventSet> pending;
+	double ms[3] = {0, 0, 0};
+	int64_t launches[3] = {0, 0, 0};
+	int64_t stats[4] = {0, 0, 0, 0};
+	std::string err;
+};
+
+#define HIP_TRY(ctx, call)                                                                         \
+	do {                                                                                           \
+		hipError_t e_ = (call);                                                                    \
+		if (e_ != hipSuccess) {                                                                    \
+			(ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+			return CHAINDP_ERR_HIP;                                                                \
+		}                                                                                          \
+	} while (0)
+
+static Params to_params(const chaindp_params_t *p)
+{
+	Params q;
+	q.max_dist_x = p->max_dist_x; q.max_dist_y = p->max_dist_y; q.bw = p->bw; q.max_skip = p->max_skip;
+	q.min_sc = p->min_sc; q.is_cdna = p->is_cdna; q.n_segs = p->n_segs;
+	return q;
+}
+
+static int check_params(chaindp_ctx *ctx, const chaindp_params_t *par)
+{
+	if (!par) { ctx->err = "params is NULL"; return CHAINDP_ERR_ARG; }
+	// the reference compares unsigned differences against these after an int -> u64 conversion
+	// (chain.c:252); negative values would silently mean "unbounded", refuse them instead
+	if (par->max_dist_x < 0 || par->max_dist_y < 0 || par->bw < 0) {
+		ctx->err = "max_dist_x, max_dist_y and bw must be >= 0";
+		return CHAINDP_ERR_ARG;
+	}
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+extern "C" const char *chaindp_last_error(const chaindp_ctx_t *ctx)
+{
+	return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" void chaindp_destroy(chaindp_ctx_t *ctx)
+{
+	if (!ctx) return;
+	if (ctx->device >= 0) hipSetDevice(ctx->device);
+	if (ctx->stream) hipStreamSynchronize(ctx->stream);
+	for (auto &es : ctx->pending) for (int k = 0; k < es.n; ++k) hipEventDestroy(es.e[k]);
+	void *bufs[] = {ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_avgq, ctx->d_units,
+	                ctx->d_counters, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
+	for (void *b : bufs) if (b) hipFree(b);
+	if (ctx->stream) hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_t max_reads)
+{
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { g_create_error = "no HIP device visible"; return nullptr; }
+	if (device < 0 || device >= n_dev || max_anchors < 0 || max_reads < 0) { g_create_error = "bad device index or capacity"; return nullptr; }
+	chaindp_ctx *ctx = new chaindp_ctx();
+	ctx->device = device;
+	ctx->cap_anchors = max_anchors > 0 ? max_anchors : 1;
+	ctx->cap_reads = max_reads > 0 ? max_reads : 1;
+	const size_t na = (size_t)ctx->cap_anchors, nr = (size_t)ctx->cap_reads;
+	hipError_t e = hipSetDevice(device);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_off, (nr + 1) * 8);
+	if (e == hipSuccess) e = hipMalloc(&ctx->d_a, na * 16);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_n_segs, nr * 4);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_f, na * 4);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_p, na * 4);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_v, na * 4);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_tg, na * 4);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_avgq, nr * 4);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_units, (na / 2 + 1) * sizeof(Unit));
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 2 * sizeof(unsigned long long));
+	if (e != hipSuccess) {
+		g_create_error = std::string("chaindp_create: ") + hipGetErrorString(e);
+		chaindp_destroy(ctx);
+		return nullptr;
+	}
+	return ctx;
+}
+
+extern "C" int chaindp_set_ring(chaindp_ctx_t *ctx, int ring)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	if (ring != 128 && ring != 256 && ring != 512) { ctx->err = "ring must be 128, 256 or 512"; return CHAINDP_ERR_ARG; }
+	ctx->ring = ring;
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_set_profiling(chaindp_ctx_t *ctx, int on)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	ctx->prof = on != 0;
+	return CHAINDP_OK;
+}
+
+// Launch prepass + chain DP on `st` for a batch described by device pointers, using ctx's scratch.
+static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t n_reads, int64_t total,
+                         const int64_t *d_off, const void *d_a, const int32_t *d_n_segs,
+                         int32_t *d_f, int32_t *d_p, int32_t *d_v, hipStream_t st)
+{
+	int rc = check_params(ctx, par);
+	if (rc) return rc;
+	if (n_reads < 0 || total < 0) { ctx->err = "negative batch size"; return CHAINDP_ERR_ARG; }
+	if (n_reads > ctx->cap_reads || total > ctx->cap_anchors) {
+		ctx->err = "batch exceeds the capacity the context was created with";
+		return CHAINDP_ERR_CAPACITY;
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const Params q = to_params(par);
+	EventSet es; es.n = 0; es.slot0 = 0;
+	if (ctx->prof) {
+		for (int k = 0; k < 3; ++k) HIP_TRY(ctx, hipEventCreate(&es.e[k]));
+		es.n = 3;
+	}
+	HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(unsigned long long), st));
+	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[0], st));
+	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, d_off, d_a, ctx->d_avgq, ctx->d_units, ctx->d_counters, d_f, d_p, d_v, ctx->d_tg));
+	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[1], st));
+	HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, total / 2, d_off, d_a, d_n_segs, ctx->d_avgq, ctx->d_units, ctx->d_counters,
+	                                   d_f, d_p, d_v, ctx->d_tg));
+	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[2], st)); ctx->pending.push_back(es); }
+	ctx->stats[2] = total; ctx->stats[3] = n_reads;
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_upload(chaindp_ctx_t *ctx, int64_t n_reads, const int64_t *off, const chaindp_anchor_t *a,
+                              const int32_t *n_segs_per_read)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	if (n_reads < 0 || !off || (n_reads > 0 && off[0] != 0)) { ctx->err = "bad offsets"; return CHAINDP_ERR_ARG; }
+	const int64_t total = n_reads > 0 ? off[n_reads] : 0;
+	if (total < 0 || (total > 0 && !a)) { ctx->err = "bad anchors"; return CHAINDP_ERR_ARG; }
+	if (n_reads > ctx->cap_reads || total > ctx->cap_anchors) {
+		ctx->err = "batch exceeds the capacity the context was created with";
+		return CHAINDP_ERR_CAPACITY;
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+	if (total) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_a, a, (size_t)total * 16, hipMemcpyHostToDevice, ctx->stream));
+	ctx->has_n_segs = n_segs_per_read != nullptr;
+	if (n_segs_per_read && n_reads)
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_n_segs, n_segs_per_read, (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->n_reads = n_reads; ctx->total = total; ctx->ran = false;
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_run(chaindp_ctx_t *ctx, const chaindp_params_t *par)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	int rc = run_on_stream(ctx, par, ctx->n_reads, ctx->total, ctx->d_off, ctx->d_a, ctx->has_n_segs ? ctx->d_n_segs : nullptr,
+	                       ctx->d_f, ctx->d_p, ctx->d_v, ctx->stream);
+	if (rc == CHAINDP_OK) ctx->ran = true;
+	return rc;
+}
+
+extern "C" int chaindp_run_device(chaindp_ctx_t *ctx, const chaindp_params_t *par, int64_t n_reads, int64_t total_anchors,
+                                  const void *d_off, const void *d_a, const void *d_n_segs,
+                                  void *d_f, void *d_p, void *d_v, void *stream)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	if (!d_off || (total_anchors > 0 && (!d_a || !d_f || !d_p || !d_v))) { ctx->err = "NULL device pointer"; return CHAINDP_ERR_ARG; }
+	return run_on_stream(ctx, par, n_reads, total_anchors, (const int64_t*)d_off, d_a, (const int32_t*)d_n_segs,
+	                     (int32_t*)d_f, (int32_t*)d_p, (int32_t*)d_v, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+extern "C" int chaindp_sync(chaindp_ctx_t *ctx)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_download(chaindp_ctx_t *ctx, int32_t *f, int32_t *p, int32_t *v)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	if (!ctx->ran) { ctx->err = "chaindp_download before chaindp_run"; return CHAINDP_ERR_ARG; }
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const size_t bytes = (size_t)ctx->total * 4;
+	if (bytes) {
+		if (f) HIP_TRY(ctx, hipMemcpyAsync(f, ctx->d_f, bytes, hipMemcpyDeviceToHost, ctx->stream));
+		if (p) HIP_TRY(ctx, hipMemcpyAsync(p, ctx->d_p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+		if (v) HIP_TRY(ctx, hipMemcpyAsync(v, ctx->d_v, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	}
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_chain_batch(chaindp_ctx_t *ctx, const chaindp_params_t *par, int64_t n_reads, const int64_t *off,
+                                   const chaindp_anchor_t *a, const int32_t *n_segs_per_read,
+                                   int32_t *f, int32_t *p, int32_t *v)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	int rc = check_params(ctx, par);
+	if (rc) return rc;
+	if ((rc = chaindp_upload(ctx, n_reads, off, a, n_segs_per_read)) != CHAINDP_OK) return rc;
+	if ((rc = chaindp_run(ctx, par)) != CHAINDP_OK) return rc;
+	return chaindp_download(ctx, f, p, v);
+}
+
+static int compact_on_device(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t *seeds_off)
+{
+	int rc = check_params(ctx, par);
+	if (rc) return rc;
+	if (!ctx->ran) { ctx->err = "compaction before chaindp_run"; return CHAINDP_ERR_ARG; }
+	if (!seeds_off) { ctx->err = "NULL output"; return CHAINDP_ERR_ARG; }
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (!ctx->d_seeds) {
+		const size_t na = (size_t)ctx->cap_anchors, nr = (size_t)ctx->cap_reads;
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_first_child, na * 4));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_id, na * 4));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_seeds_off, (nr + 1) * 8));
+		HIP_TRY(ctx, hipMalloc(&ctx->d_seeds, na * sizeof(chaindp_seed_t)));
+	}
+	EventSet es; es.n = 0; es.slot0 = 2;
+	if (ctx->prof) {
+		for (int k = 0; k < 2; ++k) HIP_TRY(ctx, hipEventCreate(&es.e[k]));
+		es.n = 2;
+		HIP_TRY(ctx, hipEventRecord(es.e[0], ctx->stream));
+	}
+	HIP_TRY(ctx, chaindp::launch_compact(ctx->stream, to_params(par), ctx->n_reads, ctx->total, ctx->d_off, ctx->d_a, ctx->d_f, ctx->d_p,
+	                                     ctx->d_v, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds, nullptr));
+	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[1], ctx->stream)); ctx->pending.push_back(es); }
+	HIP_TRY(ctx, hipMemcpyAsync(seeds_off, ctx->d_seeds_off, (size_t)(ctx->n_reads + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->n_seeds = seeds_off[ctx->n_reads];
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_compact_offsets(chaindp_ctx_t *ctx, const chaindp_params_t *par, int64_t *seeds_off)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	return compact_on_device(ctx, par, seeds_off);
+}
+
+extern "C" int chaindp_download_seeds(chaindp_ctx_t *ctx, int64_t first_seed, int64_t n_seeds, chaindp_seed_t *dst)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	if (first_seed < 0 || n_seeds < 0 || first_seed + n_seeds > ctx->n_seeds || (n_seeds > 0 && !dst)) {
+		ctx->err = "seed range outside the last compaction";
+		return CHAINDP_ERR_ARG;
+	}
+	if (n_seeds == 0) return CHAINDP_OK;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipMemcpyAsync(dst, (const chaindp_seed_t*)ctx->d_seeds + first_seed, (size_t)n_seeds * sizeof(chaindp_seed_t),
+	                            hipMemcpyDeviceToHost, ctx->stream));
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_compact(chaindp_ctx_t *ctx, const chaindp_params_t *par, int64_t *seeds_off, chaindp_seed_t *seeds)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	if (ctx->total > 0 && !seeds) { ctx->err = "NULL output"; return CHAINDP_ERR_ARG; }
+	int rc = compact_on_device(ctx, par, seeds_off);
+	if (rc) return rc;
+	if ((rc = chaindp_download_seeds(ctx, 0, ctx->n_seeds, seeds)) != CHAINDP_OK) return rc;
+	return chaindp_sync(ctx);
+}
+
+extern "C" int chaindp_upload_gather(chaindp_ctx_t *ctx, int64_t n_reads, const int64_t *off,
+                                     const chaindp_anchor_t *const *read_anchors, const int32_t *n_segs_per_read)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	if (n_reads < 0 || !off || (n_reads > 0 && (off[0] != 0 || !read_anchors))) { ctx->err = "bad offsets"; return CHAINDP_ERR_ARG; }
+	const int64_t total = n_reads > 0 ? off[n_reads] : 0;
+	if (n_reads > ctx->cap_reads || total > ctx->cap_anchors) {
+		ctx->err = "batch exceeds the capacity the context was created with";
+		return CHAINDP_ERR_CAPACITY;
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+	for (int64_t r = 0; r < n_reads; ++r) {
+		const int64_t n = off[r + 1] - off[r];
+		if (n < 0 || (n > 0 && !read_anchors[r])) { ctx->err = "bad read in gather list"; return CHAINDP_ERR_ARG; }
+		if (n) HIP_TRY(ctx, hipMemcpyAsync((chaindp_anchor_t*)ctx->d_a + off[r], read_anchors[r], (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+	}
+	ctx->has_n_segs = n_segs_per_read != nullptr;
+	if (n_segs_per_read && n_reads)
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_n_segs, n_segs_per_read, (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->n_reads = n_reads; ctx->total = total; ctx->ran = false;
+	return CHAINDP_OK;
+}
+
+extern "C" void *chaindp_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+	return p;
+}
+
+extern "C" void chaindp_host_free(void *p)
+{
+	if (p) hipHostFree(p);
+}
+
+extern "C" int chaindp_get_kernel_ms(chaindp_ctx_t *ctx, double ms[3], int64_t launches[3], int reset)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	for (auto &es : ctx->pending) {
+		HIP_TRY(ctx, hipEventSynchronize(es.e[es.n - 1]));
+		for (int k = 0; k + 1 < es.n; ++k) {
+			float t = 0;
+			HIP_TRY(ctx, hipEventElapsedTime(&t, es.e[k], es.e[k + 1]));
+			ctx->ms[es.slot0 + k] += (double)t;
+			ctx->launches[es.slot0 + k] += 1;
+		}
+		for (int k = 0; k < es.n; ++k) hipEventDestroy(es.e[k]);
+	}
+	ctx->pending.clear();
+	for (int k = 0; k < 3; ++k) { if (ms) ms[k] = ctx->ms[k]; if (launches) launches[k] = ctx->launches[k]; }
+	if (reset) for (int k = 0; k < 3; ++k) { ctx->ms[k] = 0; ctx->launches[k] = 0; }
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_get_stats(chaindp_ctx_t *ctx, int64_t st[4])
+{
+	if (!ctx || !st) return CHAINDP_ERR_ARG;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	unsigned long long c[2] = {0, 0};
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+	ctx->stats[0] = (int64_t)c[0]; ctx->stats[1] = (int64_t)c[1];
+	for (int k = 0; k < 4; ++k) st[k] = ctx->stats[k];
+	return CHAINDP_OK;
+}

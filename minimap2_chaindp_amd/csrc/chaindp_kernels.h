@@ -1,0 +1,38 @@
+// chaindp_kernels.h -- internal interface between the C-ABI host code and the HIP kernels.
+#ifndef CHAINDP_KERNELS_H
+#define CHAINDP_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace chaindp {
+
+// arguments of mm_chain_dp_fpga (reference chain.c:218), same order as chaindp_params_t
+struct Params {
+	int32_t max_dist_x, max_dist_y, bw, max_skip, min_sc, is_cdna, n_segs;
+};
+
+// one independent DP problem: anchors [start, next gap > max_dist_x or end of read) of read `read`
+struct Unit {
+	int64_t start;   // global anchor index
+	int32_t read;
+	int32_t pad;
+};
+
+// counters[0] = number of units emitted, counters[1] = singleton anchors resolved by the prepass
+hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, const int64_t *d_off, const void *d_a,
+                          float *d_avgq, Unit *d_units, unsigned long long *d_counters,
+                          int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg);
+
+hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
+                        const int32_t *d_n_segs, const float *d_avgq, const Unit *d_units,
+                        const unsigned long long *d_counters, int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg);
+
+// compaction into new_seed[] (reference chain.c:286-317): see chaindp_compact.hip
+hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off,
+                          const void *d_a, const int32_t *d_f, const int32_t *d_p, const int32_t *d_v,
+                          int32_t *d_first_child, int32_t *d_id, int64_t *d_seeds_off, void *d_seeds,
+                          void *d_scan_tmp);
+
+} // namespace chaindp
+#endif

@@ -1,0 +1,390 @@
+// fpga_shim.cpp -- the reference's accelerator driver ABI (fpga.h:37-62) served by MI355X GPUs.
+// See include/chaindp_fpga.h for the contract and the reference call sites of each entry point.
+//
+// Structure: producers (the reference's worker threads, map.c:439-444) obtain pinned packet buffers
+// and submit them; one service thread per GPU drains the submit queue, merges up to
+// max_packets_per_batch packets into ONE device batch (reads grouped by their (gap_ref, gap_qry)
+// pair, which is uniform in practice), uploads each read's anchors straight from its pinned packet,
+// runs prepass + chain DP + compaction, and DMA-writes every read's new_seed[] straight into its
+// slot of a pinned result packet; the single consumer (recv_task_thread, fpga_chaindp.c:228) blocks
+// in fpga_get_retbuf.  Results may return in any order (map.c:930,946 match by read_id).
+#include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+#include "../../include/chaindp_fpga.h"
+
+static_assert(sizeof(chaindp_pkt_hdr_t) == 64, "chaindp_sndhdr_t must be 64 bytes (reference main.c:296-302)");
+static_assert(sizeof(chaindp_pkt_task_t) == 64, "collect_task_t must be 64 bytes");
+static_assert(sizeof(chaindp_pkt_result_t) == 64, "collect_result_t must be 64 bytes");
+static_assert(sizeof(chaindp_seed_t) == 24, "struct new_seed must be 24 bytes");
+
+namespace {
+
+struct Buf { void *p; size_t cap; };
+
+// Pinned buffers in power-of-two size classes, recycled.
+class PinnedPool {
+public:
+	void *get(size_t bytes)
+	{
+		size_t cap = 1 << 16;
+		while (cap < bytes) cap <<= 1;
+		std::lock_guard<std::mutex> g(mu_);
+		auto &fl = free_[cap];
+		void *p = nullptr;
+		if (!fl.empty()) { p = fl.back(); fl.pop_back(); }
+		else if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+		cap_of_[p] = cap;
+		return p;
+	}
+	void put(void *p)
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		auto it = cap_of_.find(p);
+		if (it == cap_of_.end()) return;
+		free_[it->second].push_back(p);
+	}
+	bool owns(void *p)
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		return cap_of_.count(p) != 0;
+	}
+	void destroy()
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		for (auto &kv : cap_of_) hipHostFree(kv.first);
+		cap_of_.clear(); free_.clear();
+	}
+private:
+	std::mutex mu_;
+	std::map<size_t, std::vector<void*>> free_;
+	std::unordered_map<void*, size_t> cap_of_;
+};
+
+struct Submitted { void *buf; uint32_t size; };
+struct Result { void *buf; int size; };
+
+struct Service {
+	bool up = false;
+	int n_gpus_cfg = 0, max_packets = 64;
+	unsigned long max_inflight = 1ul << 30;
+	// fpga_set_params (main.c:243)
+	int bw = 500, is_cdna = 0, max_skip = 25, min_sc = 40, flag = 0, max_occ = 0;
+	PinnedPool pool;
+	std::mutex mu;
+	std::condition_variable cv_submit, cv_result;
+	std::deque<Submitted> submit_q;
+	std::deque<Result> result_q;
+	unsigned long inflight_bytes = 0;
+	bool stopping = false, exit_block = false;
+	std::vector<std::thread> workers;
+	int64_t stats[5] = {0, 0, 0, 0, 0};
+	uint32_t next_magic = 0;
+};
+
+Service g;
+
+struct ReadRef {
+	const chaindp_pkt_task_t *task;
+	const chaindp_anchor_t *anchors;
+	int pkt, idx;          // position in the batch's packet list / within the packet
+	bool on_device;        // false: answered with err_flag = 1
+	int64_t batch_read;    // index in the device batch
+};
+
+void fail_hard(const char *what)
+{
+	// the reference's convention for driver failures is exit(1) (fpga_chaindp.c:105-109,246-249)
+	fprintf(stderr, "[chaindp-fpga] fatal: %s\n", what);
+	exit(1);
+}
+
+void service_loop(int device)
+{
+	const int64_t cap_anchors = 64ll << 20, cap_reads = 1 << 20;   // 1 GiB of anchors per batch at most
+	chaindp_ctx_t *ctx = chaindp_create(device, cap_anchors, cap_reads);
+	if (!ctx) { fprintf(stderr, "[chaindp-fpga] %s\n", chaindp_last_error(nullptr)); fail_hard("cannot create a device context"); }
+	std::vector<Submitted> pk;
+	std::vector<ReadRef> reads;
+	for (;;) {
+		pk.clear(); reads.clear();
+		int bw, is_cdna, max_skip, min_sc;
+		{
+			std::unique_lock<std::mutex> lk(g.mu);
+			g.cv_submit.wait(lk, [] { return g.stopping || !g.submit_q.empty(); });
+			if (g.submit_q.empty()) break;          // stopping and drained
+			int64_t anchors_est = 0;
+			while (!g.submit_q.empty() && (int)pk.size() < g.max_packets) {
+				const Submitted s = g.submit_q.front();
+				if (!pk.empty() && anchors_est + (int64_t)(s.size / 16) > cap_anchors) break;
+				anchors_est += s.size / 16;
+				pk.push_back(s); g.submit_q.pop_front();
+			}
+			bw = g.bw; is_cdna = g.is_cdna; max_skip = g.max_skip; min_sc = g.min_sc;
+		}
+		// ---- parse (map.c:484-568 walks the packet the same way)
+		for (size_t k = 0; k < pk.size(); ++k) {
+			const char *base = (const char*)pk[k].buf;
+			const chaindp_pkt_hdr_t *h = (const chaindp_pkt_hdr_t*)base;
+			const char *q = base + sizeof(chaindp_pkt_hdr_t);
+			for (int i = 0; i < (int)h->num; ++i) {
+				const chaindp_pkt_task_t *t = (const chaindp_pkt_task_t*)q;
+				ReadRef rr;
+				rr.task = t; rr.anchors = (const chaindp_anchor_t*)(q + sizeof(chaindp_pkt_task_t));
+				rr.pkt = (int)k; rr.idx = i; rr.batch_read = -1;
+				rr.on_device = h->type == CHAINDP_PKT_ANCHORS && t->seednum >= 0 && t->gap_ref >= 0 && t->gap_qry >= 0;
+				const uint64_t payload = CHAINDP_ALIGN64((uint64_t)(t->seednum > 0 ? t->seednum : 0) * sizeof(chaindp_anchor_t));
+				q += sizeof(chaindp_pkt_task_t) + payload;
+				if ((size_t)(q - base) > pk[k].size) fail_hard("task packet shorter than its headers claim");
+				reads.push_back(rr);
+			}
+		}
+		// ---- group by (gap_ref, gap_qry): one device batch per distinct pair
+		std::map<std::pair<int, int>, std::vector<size_t>> groups;
+		for (size_t r = 0; r < reads.size(); ++r)
+			if (reads[r].on_device) groups[{reads[r].task->gap_ref, reads[r].task->gap_qry}].push_back(r);
+		// Result packets can only be laid out once every read's new_i is known, and the device holds one
+		// group's results at a time, so each group's new_seed[] is staged in pinned memory first.
+		std::vector<int64_t> n_a(reads.size(), 0);
+		std::vector<void*> group_stage;
+		std::vector<std::vector<int64_t>> group_off;
+		std::vector<const std::vector<size_t>*> group_reads;
+		for (auto &kv : groups) {
+			const std::vector<size_t> &idx = kv.second;
+			chaindp_params_t par;
+			par.max_dist_x = kv.first.first; par.max_dist_y = kv.first.second; par.bw = bw; par.max_skip = max_skip;
+			par.min_sc = min_sc; par.is_cdna = is_cdna; par.n_segs = 1;
+			std::vector<int64_t> off(idx.size() + 1, 0);
+			std::vector<const chaindp_anchor_t*> ptrs(idx.size());
+			std::vector<int32_t> nseg(idx.size());
+			for (size_t k = 0; k < idx.size(); ++k) {
+				const ReadRef &rr = reads[idx[k]];
+				off[k + 1] = off[k] + rr.task->seednum;
+				ptrs[k] = rr.anchors;
+				nseg[k] = rr.task->n_segs;
+			}
+			std::vector<int64_t> soff(idx.size() + 1, 0);
+			int rc = chaindp_upload_gather(ctx, (int64_t)idx.size(), off.data(), ptrs.data(), nseg.data());
+			if (rc == CHAINDP_OK) rc = chaindp_run(ctx, &par);
+			if (rc == CHAINDP_OK) rc = chaindp_compact_offsets(ctx, &par, soff.data());
+			void *stage = nullptr;
+			if (rc == CHAINDP_OK) {
+				const int64_t m = soff[idx.size()];
+				stage = g.pool.get((size_t)(m > 0 ? m : 1) * sizeof(chaindp_seed_t));
+				if (!stage) fail_hard("out of pinned memory");
+				rc = chaindp_download_seeds(ctx, 0, m, (chaindp_seed_t*)stage);
+				if (rc == CHAINDP_OK) rc = chaindp_sync(ctx);
+			}
+			if (rc != CHAINDP_OK) { fprintf(stderr, "[chaindp-fpga] %s\n", chaindp_last_error(ctx)); fail_hard("device batch failed"); }
+			for (size_t k = 0; k < idx.size(); ++k) n_a[idx[k]] = soff[k + 1] - soff[k];
+			group_stage.push_back(stage); group_off.push_back(std::move(soff)); group_reads.push_back(&idx);
+			std::lock_guard<std::mutex> lk(g.mu);
+			g.stats[3] += 1;
+		}
+		// where each read's seeds sit in its group's staging buffer
+		std::vector<const chaindp_seed_t*> seed_src(reads.size(), nullptr);
+		for (size_t gi = 0; gi < group_reads.size(); ++gi)
+			for (size_t k = 0; k < group_reads[gi]->size(); ++k)
+				seed_src[(*group_reads[gi])[k]] = (const chaindp_seed_t*)group_stage[gi] + group_off[gi][k];
+		// ---- result packets (map.c:494-567 writes them the same way; parsed at map.c:918-931)
+		size_t r0 = 0;
+		int64_t n_reads_done = 0, n_anchors_done = 0, n_err = 0;
+		std::vector<Result> out;
+		for (size_t k = 0; k < pk.size(); ++k) {
+			const chaindp_pkt_hdr_t *h = (const chaindp_pkt_hdr_t*)pk[k].buf;
+			size_t bytes = sizeof(chaindp_pkt_hdr_t);
+			for (int i = 0; i < (int)h->num; ++i) {
+				const ReadRef &rr = reads[r0 + i];
+				bytes += sizeof(chaindp_pkt_result_t);
+				if (rr.on_device) bytes += CHAINDP_ALIGN64((uint64_t)n_a[r0 + i] * sizeof(chaindp_seed_t));
+			}
+			char *ob = (char*)g.pool.get(bytes);
+			if (!ob) fail_hard("out of pinned memory");
+			chaindp_pkt_hdr_t *oh = (chaindp_pkt_hdr_t*)ob;
+			memset(oh, 0, sizeof(*oh));
+			oh->magic = h->magic; oh->size = (uint32_t)bytes; oh->tid = h->tid; oh->num = h->num; oh->type = h->type; oh->lat = h->lat;
+			char *q = ob + sizeof(chaindp_pkt_hdr_t);
+			for (int i = 0; i < (int)h->num; ++i) {
+				const ReadRef &rr = reads[r0 + i];
+				chaindp_pkt_result_t *res = (chaindp_pkt_result_t*)q;
+				memset(res, 0, sizeof(*res));
+				res->read_id = rr.task->read_id;
+				q += sizeof(chaindp_pkt_result_t);
+				if (!rr.on_device) {
+					res->err_flag = 1; res->sub_size = sizeof(chaindp_pkt_result_t);   // header only (map.c:970-971)
+					++n_err;
+				} else {
+					const uint64_t sb = (uint64_t)n_a[r0 + i] * sizeof(chaindp_seed_t), sp = CHAINDP_ALIGN64(sb);
+					res->n_a = (uint32_t)n_a[r0 + i];
+					res->sub_size = (uint32_t)(sizeof(chaindp_pkt_result_t) + sp);
+					if (sb) memcpy(q, seed_src[r0 + i], sb);
+					if (sp > sb) memset(q + sb, 0, sp - sb);
+					q += sp;
+					n_anchors_done += rr.task->seednum;
+				}
+				++n_reads_done;
+			}
+			r0 += h->num;
+			out.push_back(Result{ob, (int)bytes});
+		}
+		for (void *s : group_stage) g.pool.put(s);
+		{
+			std::lock_guard<std::mutex> lk(g.mu);
+			for (size_t k = 0; k < pk.size(); ++k) { g.inflight_bytes -= pk[k].size; g.pool.put(pk[k].buf); }
+			for (auto &r : out) g.result_q.push_back(r);
+			g.stats[0] += (int64_t)pk.size(); g.stats[1] += n_reads_done; g.stats[2] += n_anchors_done; g.stats[4] += n_err;
+		}
+		g.cv_result.notify_all();
+	}
+	chaindp_destroy(ctx);
+}
+
+} // namespace
+
+extern "C" void chaindp_fpga_configure(int n_gpus, int max_packets_per_batch, unsigned long max_inflight_bytes)
+{
+	std::lock_guard<std::mutex> lk(g.mu);
+	g.n_gpus_cfg = n_gpus;
+	if (max_packets_per_batch > 0) g.max_packets = max_packets_per_batch;
+	if (max_inflight_bytes > 0) g.max_inflight = max_inflight_bytes;
+}
+
+extern "C" void chaindp_fpga_stats(int64_t st[5])
+{
+	std::lock_guard<std::mutex> lk(g.mu);
+	for (int k = 0; k < 5; ++k) st[k] = g.stats[k];
+}
+
+extern "C" int fpga_init(int flag)
+{
+	(void)flag;   // BLOCK / NOBLOCK (fpga.h:11-12): the receive side is always blocking until fpga_exit_block
+	std::lock_guard<std::mutex> lk(g.mu);
+	if (g.up) return 0;
+	int n = chaindp_device_count();
+	if (n <= 0) {
+		fprintf(stderr, "[chaindp-fpga] fpga_init: no MI355X visible to this process; there is no CPU fallback in this library\n");
+		return -1;
+	}
+	if (g.n_gpus_cfg > 0 && g.n_gpus_cfg < n) n = g.n_gpus_cfg;
+	g.stopping = false; g.exit_block = false;
+	for (int k = 0; k < 5; ++k) g.stats[k] = 0;
+	for (int d = 0; d < n; ++d) g.workers.emplace_back(service_loop, d);
+	g.up = true;
+	return 0;
+}
+
+extern "C" void fpga_finalize(void)
+{
+	{
+		std::lock_guard<std::mutex> lk(g.mu);
+		if (!g.up) return;
+		g.stopping = true;
+	}
+	g.cv_submit.notify_all();
+	for (auto &t : g.workers) t.join();
+	g.workers.clear();
+	{
+		std::lock_guard<std::mutex> lk(g.mu);
+		g.submit_q.clear(); g.result_q.clear(); g.inflight_bytes = 0;
+		g.up = false;
+	}
+	g.pool.destroy();
+}
+
+extern "C" void fpga_set_params(int bw, int is_cdna, int max_skip, int min_sc, int flag, int max_occ)
+{
+	std::lock_guard<std::mutex> lk(g.mu);
+	g.bw = bw; g.is_cdna = is_cdna; g.max_skip = max_skip; g.min_sc = min_sc; g.flag = flag; g.max_occ = max_occ;
+}
+
+extern "C" void fpga_load_index(void *addr, int size, int type)
+{
+	// index.c:102-119 streams the B/H/V/P index image (types 4..7) to the FPGA, which did the seed
+	// lookup itself.  Here seed collection stays on the host, so the image is not needed.
+	(void)addr; (void)size; (void)type;
+}
+
+extern "C" void *fpga_get_writebuf_thread(unsigned long size, int type, int tid)
+{
+	(void)type; (void)tid;
+	{
+		std::lock_guard<std::mutex> lk(g.mu);
+		if (!g.up) fail_hard("fpga_get_writebuf_thread before a successful fpga_init (a NULL here would make the caller retry forever, map.c:439)");
+		if (g.inflight_bytes + size > g.max_inflight && g.inflight_bytes > 0) return nullptr;   // busy: caller usleep(50)s and retries
+		g.inflight_bytes += size;
+	}
+	void *p = g.pool.get(size);
+	if (!p) {
+		std::lock_guard<std::mutex> lk(g.mu);
+		g.inflight_bytes -= size;
+	}
+	return p;
+}
+
+extern "C" void *fpga_get_writebuf(unsigned long size, int type)
+{
+	{
+		std::lock_guard<std::mutex> lk(g.mu);
+		if (!g.up) {
+			fprintf(stderr, "[chaindp-fpga] fpga_get_writebuf before a successful fpga_init\n");
+			return nullptr;                       // the reference exit(1)s on NULL here (fpga_chaindp.c:105-109)
+		}
+	}
+	return fpga_get_writebuf_thread(size, type, -1);
+}
+
+extern "C" int fpga_writebuf_submit(void *addr, unsigned int size, unsigned int type)
+{
+	(void)type;   // callers pass TYPE_CD while the header says 3 (map.c:302,444); the header decides
+	if (!addr || size < sizeof(chaindp_pkt_hdr_t) || !g.pool.owns(addr)) return -1;
+	{
+		std::lock_guard<std::mutex> lk(g.mu);
+		if (!g.up) return -1;
+		chaindp_pkt_hdr_t *h = (chaindp_pkt_hdr_t*)addr;
+		if (h->magic == 0) h->magic = g.next_magic++;      // send_task_thread numbered packets (fpga_chaindp.c:99-100)
+		g.submit_q.push_back(Submitted{addr, size});
+	}
+	g.cv_submit.notify_one();
+	return 0;
+}
+
+extern "C" void *fpga_get_retbuf(int *len, int type)
+{
+	(void)type;
+	std::unique_lock<std::mutex> lk(g.mu);
+	g.cv_result.wait(lk, [] { return !g.result_q.empty() || g.exit_block || !g.up; });
+	if (g.result_q.empty()) { if (len) *len = 0; return nullptr; }   // fpga_exit_block: len == 0 ends recv_task_thread (fpga_chaindp.c:242)
+	Result r = g.result_q.front();
+	g.result_q.pop_front();
+	if (len) *len = r.size;
+	return r.buf;
+}
+
+extern "C" int fpga_release_retbuf(void *addr)
+{
+	if (!addr || !g.pool.owns(addr)) return -1;
+	g.pool.put(addr);
+	return 0;
+}
+
+extern "C" void fpga_exit_block(void)
+{
+	{ std::lock_guard<std::mutex> lk(g.mu); g.exit_block = true; }
+	g.cv_result.notify_all();
+}
+
+extern "C" void fpga_set_block(void)
+{
+	std::lock_guard<std::mutex> lk(g.mu);
+	g.exit_block = false;
+}

@@ -1,0 +1,127 @@
+"""GPU tier: the HIP path, called through the C ABI (libchaindp_hip.so), against the golden vectors
+of the reference and against the oracle on seeded batches.  Bit-exact: integer arrays are compared
+with array_equal, new_seed[] by bytes."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import golden_names, load_golden, params_from
+from minimap2_chaindp_amd import anchorgen as ag, chaindp, params as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    with chaindp.Device(0, max_anchors=1 << 23, max_reads=1 << 16) as d:
+        yield d
+
+
+@pytest.mark.parametrize("ring", [128, 256, 512])
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fixture_bit_exact(dev, name, ring):
+    g = load_golden(name)
+    par = params_from(g["params"])
+    dev._check(dev._lib.chaindp_set_ring(dev._ctx, ring))
+    f, p, v = dev.chain_batch(par, g["off"], g["anchors"])
+    assert np.array_equal(f, g["f"]), (name, "f", int(np.flatnonzero(f != g["f"])[0]))
+    assert np.array_equal(p, g["p"]), (name, "p", int(np.flatnonzero(p != g["p"])[0]))
+    assert np.array_equal(v, g["v"]), (name, "v", int(np.flatnonzero(v != g["v"])[0]))
+    soff, seeds = dev.compact(par)
+    assert np.array_equal(soff, g["seeds_off"]), (name, "new_i")
+    assert seeds.tobytes() == g["seeds"].tobytes(), (name, "new_seed[] bytes")
+
+
+CASES = [  # generator, generator overrides, DP preset, DP overrides, reads, per-read n_segs?
+    ("ava-ont", {}, "ava-ont", {}, 300, False),
+    ("map-ont", {}, "map-ont", {}, 200, False),
+    ("ties", {}, "map-ont", {}, 200, False),
+    ("ties", {}, "splice", {}, 100, False),
+    ("ties", {}, "ava-pb", {}, 100, False),
+    ("paired", {}, "sr", {}, 2000, False),
+    ("paired", {}, "map-ont", dict(n_segs=2), 500, True),
+    ("dense", dict(read_len=3000, n_hits=12), "ava-ont", {}, 6, False),
+    ("skew", dict(skew_max=30000), "ava-ont", {}, 100, False),
+    ("ties", {}, "map-ont", dict(max_skip=0), 50, False),
+    ("ties", {}, "map-ont", dict(max_skip=2, bw=30), 50, False),
+]
+
+
+@pytest.mark.parametrize("gen,gen_over,preset,par_over,n_reads,per_read", CASES)
+def test_seeded_batches_match_oracle(dev, gen, gen_over, preset, par_over, n_reads, per_read):
+    dev._check(dev._lib.chaindp_set_ring(dev._ctx, 256))
+    par = P.preset(preset, **par_over)
+    off, a = ag.generate(gen, n_reads=n_reads, seed=1234, **gen_over)
+    n_segs = None
+    if per_read:   # collect_task_t::n_segs is per read (fpga_chaindp.h:53): mix 1 and 2
+        n_segs = (np.arange(n_reads) % 2 + 1).astype(np.int32)
+    f, p, v = dev.chain_batch(par, off, a, n_segs=n_segs)
+    of, op, ov, _ = ol.oracle_batch(par, off, a, n_segs=n_segs, threads=8)
+    for name, x, y in (("f", f, of), ("p", p, op), ("v", v, ov)):
+        bad = np.flatnonzero(x != y)
+        assert bad.size == 0, (gen, preset, name, "first mismatch at anchor", int(bad[0]), int(x[bad[0]]), int(y[bad[0]]),
+                               "read", int(np.searchsorted(off, bad[0], side="right") - 1))
+    soff, seeds = dev.compact(par)
+    assert int(soff[-1]) == len(seeds)
+    for r in range(0, n_reads, max(1, n_reads // 25)):
+        lo, hi = int(off[r]), int(off[r + 1])
+        rp = P.preset(preset, **par_over)
+        if n_segs is not None:
+            rp.n_segs = int(n_segs[r])
+        exp = ol.oracle_compact(rp, np.ascontiguousarray(a[lo:hi]), of[lo:hi].copy(), op[lo:hi].copy(), ov[lo:hi].copy())
+        assert seeds[int(soff[r]):int(soff[r + 1])].tobytes() == exp.tobytes(), (gen, preset, r)
+
+
+def test_edge_batches(dev):
+    par = P.preset("map-ont")
+    # empty batch, batch of empty reads, a single one-anchor read
+    f, p, v = dev.chain_batch(par, np.zeros(1, np.int64), np.zeros((0, 2), np.uint64))
+    assert len(f) == 0
+    f, p, v = dev.chain_batch(par, np.zeros(4, np.int64), np.zeros((0, 2), np.uint64))
+    assert len(f) == 0
+    soff, seeds = dev.compact(par)
+    assert list(soff) == [0, 0, 0, 0] and len(seeds) == 0
+    a = np.array([[10, (15 << 32) | 20]], np.uint64)
+    f, p, v = dev.chain_batch(par, np.array([0, 1], np.int64), a)
+    assert (int(f[0]), int(p[0]), int(v[0])) == (15, -1, 15)
+
+
+def test_big_span_sum_rounding(dev):
+    """avg_qspan = (float)sum_qspan / n with sum_qspan > 2^24: the u64 -> f32 conversion must round
+    like the host's (chain.c:241).  One read of 120k anchors with span 255/254 mixed."""
+    n = 120_000
+    rng = np.random.default_rng(1)
+    span = np.where(rng.random(n) < 0.37, 254, 255).astype(np.uint64)
+    x = np.cumsum(rng.integers(1, 9, n)).astype(np.uint64)
+    q = (np.cumsum(rng.integers(1, 9, n)) + 300).astype(np.uint64)
+    a = np.stack([x, (span << np.uint64(32)) | q], 1)
+    off = np.array([0, n], np.int64)
+    par = P.preset("map-ont")
+    f, p, v = dev.chain_batch(par, off, a)
+    of, op, ov, _ = ol.oracle_fpv(par, a)
+    assert np.array_equal(f, of) and np.array_equal(p, op) and np.array_equal(v, ov)
+
+
+def test_rejects_bad_arguments(dev):
+    par = P.preset("map-ont", max_dist_x=-1)
+    with pytest.raises(chaindp.ChainDPError):
+        dev.chain_batch(par, np.array([0, 1], np.int64), np.array([[1, 1]], np.uint64))
+    with pytest.raises(chaindp.ChainDPError):   # capacity
+        small = chaindp.Device(0, max_anchors=10, max_reads=2)
+        try:
+            small.chain_batch(P.preset("map-ont"), np.array([0, 20], np.int64), np.zeros((20, 2), np.uint64))
+        finally:
+            small.close()
+
+
+def test_run_is_idempotent_and_staged_api(dev):
+    par = P.preset("ava-ont")
+    off, a = ag.generate("ava-ont", n_reads=50, seed=77)
+    dev.upload(off, a)
+    dev.run(par); dev.sync()
+    f1, p1, v1 = dev.download()
+    dev.run(par); dev.run(par); dev.sync()
+    f2, p2, v2 = dev.download()
+    assert np.array_equal(f1, f2) and np.array_equal(p1, p2) and np.array_equal(v1, v2)
+    st = dev.stats()
+    assert st["anchors"] == int(off[-1]) and st["reads"] == 50 and st["units"] > 0

@@ -1,0 +1,65 @@
+"""Build-container tier: the oracle against the UNMODIFIED reference compiled from
+/root/reference (oracle/_ref, `make -C oracle ref`).  Skipped where the reference build is
+absent.  On the GPU box the prebuilt oracle/_ref/*.so travel with the snapshot, so this also
+runs there (CPU only, no GPU needed)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from minimap2_chaindp_amd import anchorgen as ag, params as P
+
+pytestmark = pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+
+CASES = [  # generator preset, generator overrides, DP preset, DP overrides, reads
+    ("ava-ont", {}, "ava-ont", {}, 6),
+    ("map-ont", {}, "map-ont", {}, 6),
+    ("ties", {}, "map-ont", {}, 10),
+    ("ties", {}, "splice", {}, 8),
+    ("ties", {}, "ava-pb", {}, 8),
+    ("paired", {}, "sr", {}, 60),
+    ("paired", {}, "map-ont", dict(n_segs=2), 30),
+    ("dense", dict(read_len=2500, n_hits=10), "ava-ont", {}, 1),
+    ("skew", dict(skew_max=20000), "ava-ont", {}, 12),
+]
+
+
+@pytest.mark.parametrize("gen,gen_over,preset,par_over,n_reads", CASES)
+def test_oracle_equals_reference(gen, gen_over, preset, par_over, n_reads):
+    par = P.preset(preset, **par_over)
+    off, a = ag.generate(gen, n_reads=n_reads, seed=99, threads=2, **gen_over)
+    for r in range(n_reads):
+        ar = np.ascontiguousarray(a[off[r]:off[r + 1]])
+        f, p, v, _ = ol.oracle_fpv(par, ar)
+        rf, rp, rv, rs = ol.ref_fpv_seeds(par, ar)
+        assert np.array_equal(f, rf) and np.array_equal(p, rp) and np.array_equal(v, rv), (gen, preset, r)
+        s = ol.oracle_compact(par, ar, f, p, v)
+        assert s.tobytes() == rs.tobytes(), (gen, preset, r, "new_seed")
+        u1, b1 = ol.oracle_bottom(3, par.min_sc, s)
+        u2, b2 = ol.ref_bottom(3, par.min_sc, par.n_segs, rs)
+        assert np.array_equal(u1, u2) and np.array_equal(b1, b2), (gen, preset, r, "bottom")
+
+
+def test_radix_sorts_follow_reference_order():
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 7, 64, 65, 300, 5000):
+        # few distinct keys -> many ties -> the unstable order is observable through y
+        x = rng.integers(0, 40, n).astype(np.uint64) << np.uint64(rng.integers(0, 56))
+        a = np.stack([x, np.arange(n, dtype=np.uint64)], 1).copy()
+        b = a.copy()
+        ol.oracle().co_radix_sort_128x(a.ctypes.data, a.ctypes.data + a.nbytes)
+        ol.ref_cap().radix_sort_128x(b.ctypes.data, b.ctypes.data + b.nbytes)
+        assert np.array_equal(a, b), n
+        u = rng.integers(0, 2**63, n).astype(np.uint64)
+        w = u.copy()
+        ol.oracle().co_radix_sort_64(u.ctypes.data, u.ctypes.data + u.nbytes)
+        ol.ref_cap().radix_sort_64(w.ctypes.data, w.ctypes.data + w.nbytes)
+        assert np.array_equal(u, w) and np.all(u[:-1] <= u[1:])
+
+
+def test_oracle_speed_is_not_a_straw_man():
+    """the restatement timed beside the reference's own code."""
+    par = P.preset("ava-ont")
+    off, a = ag.generate("ava-ont", n_reads=60, seed=4)
+    t_ref, _ = ol.time_top(par, off, a, threads=1, use_ref=True)
+    t_ora, _ = ol.time_top(par, off, a, threads=1, use_ref=False)
+    assert t_ora < 1.5 * t_ref, (t_ora, t_ref)
