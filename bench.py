@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- chained anchors/s of the device half of minimap2's chaining (reference chain.c:218-327)
+on N MI355X, one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[3], "ava-ont self-overlap, 100k synthetic 10 kb reads, read-sharded
+across 8 GPUs"): every rank holds the same-size shard of that job, 12,500 reads (~6.1k anchors per
+read), generated on the host with the rank's read indices and the job's seed, uploaded to HBM
+BEFORE the clock starts.  A step = one pass of the whole device half over the resident shard:
+prepass (unit split, avg_qspan sums) + chain DP (f/p/v) + compaction into new_seed[], all HIP
+kernels, results left in HBM.  Reads are independent, so there is no collective on the data path
+(weak scaling); torch.distributed (RCCL) only provides the barrier and the max-over-ranks time.
+
+One JSON line on rank 0: metric/value/unit as BASELINE.json names them, plus
+  roofline     -- the chain-DP kernel against the HBM roofline: 24 algorithmic bytes per anchor
+                  (16 B mm128_t read + 4 B f + 4 B p written) over its average launch
+                  duration, measured with HIP events on the kernel's own stream.
+  cpu_baseline -- the reference's mm_chain_dp_fpga (oracle/_ref, compiled from /root/reference in the
+                  build container) or, if that file is absent, the oracle's port of it, timed on all
+                  host cores over a bounded sample of the same batch (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+READS_PER_GPU = 12_500          # 100k reads / 8 GPUs (configs[3])
+SEED = 20261004
+ALGO_BYTES_PER_ANCHOR = 24
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads-per-gpu", type=int, default=READS_PER_GPU)
+    ap.add_argument("--preset", default="ava-ont", help="generator + DP preset (ava-ont, map-ont, skew)")
+    ap.add_argument("--ring", type=int, default=0, help="LDS ring capacity override (128/256/512)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-anchors", type=int, default=40_000_000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    from minimap2_chaindp_amd import anchorgen, chaindp, params
+
+    if not torch.cuda.is_available() or chaindp.device_count() <= 0:
+        raise SystemExit("bench.py needs a GPU: the chaining DP has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    gen_preset = args.preset
+    dp_preset = "ava-ont" if args.preset == "skew" else args.preset
+    par = params.preset(dp_preset)
+
+    # ---- this rank's shard of the job, generated on the host, then made resident in HBM
+    n_reads = args.reads_per_gpu
+    t_gen = time.time()
+    off, anchors = anchorgen.generate(gen_preset, n_reads=n_reads, seed=SEED, first_read=rank * n_reads)
+    t_gen = time.time() - t_gen
+    total = int(off[-1])
+    dev = chaindp.Device(local_rank, max_anchors=total + 1, max_reads=n_reads + 1, ring=args.ring or None)
+    t_up = time.time()
+    dev.upload(off, anchors)
+    t_up = time.time() - t_up
+
+    def barrier():
+        torch.cuda.synchronize()
+        dev.sync()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        dev.run_full(par)
+    barrier()
+    dev.set_profiling(True)
+    dev.kernel_ms(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dev.run_full(par)
+    dev.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kms = dev.kernel_ms(reset=True)
+    dev.set_profiling(False)
+    stats = dev.stats()
+
+    # max over ranks of the timed region; sum of anchors
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_max = float(t.item())
+        n = torch.tensor([total], dtype=torch.int64, device="cuda")
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        total_all = int(n.item())
+        dist.barrier()
+    else:
+        elapsed_max, total_all = elapsed, total
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        value = total_all * steps / elapsed_max
+        dp_ms = kms["chain_dp"][0] / max(kms["chain_dp"][1], 1)
+        pre_ms = kms["prepass"][0] / max(kms["prepass"][1], 1)
+        cmp_ms = kms["compact"][0] / max(kms["compact"][1], 1)
+        achieved = ALGO_BYTES_PER_ANCHOR * total / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
+        out = {
+            "metric": "chained anchors/sec (whole node)",
+            "value": value,
+            "unit": "anchors/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{gen_preset} synthetic anchors, {n_reads} reads x 10 kb per GPU "
+                            f"(shard of BASELINE configs[3]: 100k reads over 8 GPUs), DP preset {dp_preset}",
+                "reads_per_gpu": n_reads, "anchors_per_gpu": total, "anchors_total": total_all,
+                "units_per_gpu": stats["units"], "singletons_per_gpu": stats["singletons"],
+                "seed": SEED, "parallelism": f"reads sharded over {world} GPU(s), no collective",
+                "step": "prepass + chain DP + compaction (new_seed[]), inputs and outputs resident in HBM",
+            },
+            "roofline": {
+                "kernel": "k_chain_units", "bound": "hbm",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_anchor": ALGO_BYTES_PER_ANCHOR, "anchors_per_launch": total,
+                "avg_launch_ms": dp_ms,
+            },
+            "kernel_ms": {"prepass": pre_ms, "chain_dp": dp_ms, "compact": cmp_ms},
+            "host": {"generate_s": t_gen, "upload_s": t_up, "upload_GBps": total * 16 / t_up / 1e9 if t_up > 0 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(par, off, anchors, args.cpu_sample_anchors)
+        print(json.dumps(out), flush=True)
+
+    dev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(par, off, anchors, sample_anchors):
+    """The reference's per-read call (malloc, recurrence, compaction, free) on all host cores, over the
+    first reads of the same batch that hold about `sample_anchors` anchors."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    n = int(np.searchsorted(off, sample_anchors, side="left"))
+    n = max(1, min(n, len(off) - 1))
+    soff = np.ascontiguousarray(off[:n + 1])
+    sa = np.ascontiguousarray(anchors[:int(soff[-1])])
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    use_ref = ol.have_ref()
+    sec, _ = ol.time_top(par, soff, sa, threads=cores, use_ref=use_ref)
+    sec1, _ = ol.time_top(par, soff[:max(2, n // cores + 1)], sa, threads=1, use_ref=use_ref)
+    n1 = int(soff[max(1, n // cores)])
+    return {
+        "value": int(soff[-1]) / sec, "unit": "anchors/s", "cores": cores,
+        "kind": "reference" if use_ref else "port",
+        "sample": f"first {n} reads ({int(soff[-1])} anchors) of the same batch, per-read mm_chain_dp_fpga-shaped call "
+                  f"(malloc + recurrence + compaction + free), reads dealt to {cores} threads by anchor count",
+        "seconds": sec,
+        "single_core_value": n1 / sec1 if sec1 > 0 else None,
+    }
+
+
+if __name__ == "__main__":
+    main()

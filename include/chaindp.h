@@ -84,6 +84,11 @@ int chaindp_download(chaindp_ctx_t *ctx, int32_t *f, int32_t *p, int32_t *v);
  * chaindp_run on the same batch. */
 int chaindp_compact(chaindp_ctx_t *ctx, const chaindp_params_t *par, int64_t *seeds_off, chaindp_seed_t *seeds);
 
+/* chaindp_run followed by the compaction kernels, all asynchronous on the context's stream and
+ * with every result left in HBM: the whole device half of the reference's split (chain.c:218-327)
+ * for a resident batch.  This is what bench.py times. */
+int chaindp_run_full(chaindp_ctx_t *ctx, const chaindp_params_t *par);
+
 /* Scatter/gather variants used by the packet shim, whose reads sit in separate (pinned) packet
  * buffers: upload from one host pointer per read; run the compaction and return only the offsets;
  * then copy each read's new_seed[] straight to its place in a result packet (asynchronous on the

@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     "chaindp_upload", "chaindp_run", "chaindp_sync", "chaindp_download", "chaindp_compact",
     "chaindp_upload_gather", "chaindp_compact_offsets", "chaindp_download_seeds", "chaindp_host_alloc",
     "chaindp_host_free", "chaindp_run_device", "chaindp_set_profiling", "chaindp_get_kernel_ms",
-    "chaindp_get_stats", "chaindp_set_ring",
+    "chaindp_get_stats", "chaindp_set_ring", "chaindp_run_full",
 )
 
 
@@ -51,6 +51,7 @@ def lib():
         L.chaindp_chain_batch.argtypes = [vp, P, i64, vp, vp, vp, vp, vp, vp]
         L.chaindp_upload.argtypes = [vp, i64, vp, vp, vp]
         L.chaindp_run.argtypes = [vp, P]
+        L.chaindp_run_full.argtypes = [vp, P]
         L.chaindp_sync.argtypes = [vp]
         L.chaindp_download.argtypes = [vp, vp, vp, vp]
         L.chaindp_compact.argtypes = [vp, P, vp, vp]
@@ -145,6 +146,10 @@ class Device:
 
     def run(self, par):
         self._check(self._lib.chaindp_run(self._ctx, C.byref(par)))
+
+    def run_full(self, par):
+        """run() + the compaction kernels, asynchronous, results stay in HBM (the benchmark's step)."""
+        self._check(self._lib.chaindp_run_full(self._ctx, C.byref(par)))
 
     def sync(self):
         self._check(self._lib.chaindp_sync(self._ctx))

@@ -32,9 +32,10 @@ struct chaindp_ctx {
 	int32_t *d_f = nullptr, *d_p = nullptr, *d_v = nullptr;
 	// scratch
 	int32_t *d_tg = nullptr;
-	float *d_avgq = nullptr;
+	unsigned long long *d_sumq = nullptr;
 	Unit *d_units = nullptr;
 	unsigned long long *d_counters = nullptr;
+	chaindp::PrepassScratch pre = {nullptr, nullptr, nullptr};
 	// compaction (allocated on first use)
 	int32_t *d_first_child = nullptr, *d_id = nullptr;
 	int64_t *d_seeds_off = nullptr;
@@ -95,8 +96,8 @@ extern "C" void chaindp_destroy(chaindp_ctx_t *ctx)
 	if (ctx->device >= 0) hipSetDevice(ctx->device);
 	if (ctx->stream) hipStreamSynchronize(ctx->stream);
 	for (auto &es : ctx->pending) for (int k = 0; k < es.n; ++k) hipEventDestroy(es.e[k]);
-	void *bufs[] = {ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_avgq, ctx->d_units,
-	                ctx->d_counters, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
+	void *bufs[] = {ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_sumq, ctx->d_units,
+	                ctx->d_counters, ctx->pre.start_mask, ctx->pre.block_units, ctx->pre.block_singles, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
 	for (void *b : bufs) if (b) hipFree(b);
 	if (ctx->stream) hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -121,9 +122,14 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_p, na * 4);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_v, na * 4);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_tg, na * 4);
-	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_avgq, nr * 4);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_sumq, nr * 8);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_units, (na / 2 + 1) * sizeof(Unit));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 2 * sizeof(unsigned long long));
+	size_t mask_bytes = 0, blocks_bytes = 0;
+	chaindp::prepass_scratch_bytes(ctx->cap_anchors, &mask_bytes, &blocks_bytes);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.start_mask, mask_bytes);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.block_units, blocks_bytes);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.block_singles, blocks_bytes);
 	if (e != hipSuccess) {
 		g_create_error = std::string("chaindp_create: ") + hipGetErrorString(e);
 		chaindp_destroy(ctx);
@@ -166,11 +172,10 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		for (int k = 0; k < 3; ++k) HIP_TRY(ctx, hipEventCreate(&es.e[k]));
 		es.n = 3;
 	}
-	HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(unsigned long long), st));
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[0], st));
-	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, d_off, d_a, ctx->d_avgq, ctx->d_units, ctx->d_counters, d_f, d_p, d_v, ctx->d_tg));
+	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, d_f, d_p, d_v, ctx->d_tg));
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[1], st));
-	HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, total / 2, d_off, d_a, d_n_segs, ctx->d_avgq, ctx->d_units, ctx->d_counters,
+	HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, total / 2, d_off, d_a, d_n_segs, ctx->d_sumq, ctx->d_units, ctx->d_counters,
 	                                   d_f, d_p, d_v, ctx->d_tg));
 	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[2], st)); ctx->pending.push_back(es); }
 	ctx->stats[2] = total; ctx->stats[3] = n_reads;
@@ -253,12 +258,12 @@ extern "C" int chaindp_chain_batch(chaindp_ctx_t *ctx, const chaindp_params_t *p
 	return chaindp_download(ctx, f, p, v);
 }
 
-static int compact_on_device(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t *seeds_off)
+// launches the compaction kernels on the context's stream (asynchronous)
+static int compact_launch(chaindp_ctx *ctx, const chaindp_params_t *par)
 {
 	int rc = check_params(ctx, par);
 	if (rc) return rc;
 	if (!ctx->ran) { ctx->err = "compaction before chaindp_run"; return CHAINDP_ERR_ARG; }
-	if (!seeds_off) { ctx->err = "NULL output"; return CHAINDP_ERR_ARG; }
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	if (!ctx->d_seeds) {
 		const size_t na = (size_t)ctx->cap_anchors, nr = (size_t)ctx->cap_reads;
@@ -276,10 +281,26 @@ static int compact_on_device(chaindp_ctx *ctx, const chaindp_params_t *par, int6
 	HIP_TRY(ctx, chaindp::launch_compact(ctx->stream, to_params(par), ctx->n_reads, ctx->total, ctx->d_off, ctx->d_a, ctx->d_f, ctx->d_p,
 	                                     ctx->d_v, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds, nullptr));
 	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[1], ctx->stream)); ctx->pending.push_back(es); }
+	return CHAINDP_OK;
+}
+
+static int compact_on_device(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t *seeds_off)
+{
+	if (!seeds_off) { ctx->err = "NULL output"; return CHAINDP_ERR_ARG; }
+	int rc = compact_launch(ctx, par);
+	if (rc) return rc;
 	HIP_TRY(ctx, hipMemcpyAsync(seeds_off, ctx->d_seeds_off, (size_t)(ctx->n_reads + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	ctx->n_seeds = seeds_off[ctx->n_reads];
 	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_run_full(chaindp_ctx_t *ctx, const chaindp_params_t *par)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	int rc = chaindp_run(ctx, par);
+	if (rc) return rc;
+	return compact_launch(ctx, par);
 }
 
 extern "C" int chaindp_compact_offsets(chaindp_ctx_t *ctx, const chaindp_params_t *par, int64_t *seeds_off)

@@ -19,13 +19,20 @@ struct Unit {
 	int32_t pad;
 };
 
+// prepass scratch: one 64-bit unit-start mask per 64 anchors, per-block unit / singleton counts
+struct PrepassScratch {
+	uint64_t *start_mask;
+	uint32_t *block_units, *block_singles;
+};
+size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *blocks_bytes);
+
 // counters[0] = number of units emitted, counters[1] = singleton anchors resolved by the prepass
-hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, const int64_t *d_off, const void *d_a,
-                          float *d_avgq, Unit *d_units, unsigned long long *d_counters,
+hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off, const void *d_a,
+                          unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
                           int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg);
 
 hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
-                        const int32_t *d_n_segs, const float *d_avgq, const Unit *d_units,
+                        const int32_t *d_n_segs, const unsigned long long *d_sumq, const Unit *d_units,
                         const unsigned long long *d_counters, int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg);
 
 // compaction into new_seed[] (reference chain.c:286-317): see chaindp_compact.hip

@@ -5,10 +5,9 @@
 //   each pair, keep the running max (strictly greater wins, so ties keep the larger j), stop
 //   early once more than max_skip already-visited ("marked") predecessors failed to improve.
 // How it is computed here (DESIGN.md "Wave formulation"; modelled on the CPU in oracle/wave_model.c):
-//   * k_prepass  -- one wave per read: read-level sum of q_span -> avg_qspan (the one f32 divide,
-//                   chain.c:241); split the read into UNITS where a[i].x-a[i-1].x > max_dist_x
-//                   (independent DP problems); resolve single-anchor units on the spot; zero the
-//                   global mark array.
+//   * k_prepass  -- one thread per anchor: per-read sum of q_span (for avg_qspan, chain.c:240-241);
+//                   split each read into UNITS where a[i].x-a[i-1].x > max_dist_x (independent DP
+//                   problems); resolve single-anchor units on the spot; zero the global mark array.
 //   * k_chain_units -- one wave64 per unit.  Anchors enter in coalesced 64-anchor tiles (16 B per
 //                   lane) and live in an LDS ring (x,y,f,p,mark,v for the last RING anchors).  For
 //                   anchor i, lane k evaluates predecessor j = i-1-64c-k of chunk c; the serial
@@ -108,57 +107,144 @@ __device__ __forceinline__ void wave_global_fence()
 __device__ __forceinline__ int span_of_hi(uint32_t yhi) { return (int)(yhi & 0xffu); }        // (y>>32)&0xff
 __device__ __forceinline__ int seg_of_hi(uint32_t yhi) { return (int)((yhi >> 16) & 0xffu); } // (y>>48)&0xff
 
-// ---------------------------------------------------------------- K0: prepass
+// ---------------------------------------------------------------- K0: prepass (anchor-parallel, no hot atomics)
+// k_prepass:    one thread per anchor, PRE_PER_BLOCK consecutive anchors of the batch per block.  The
+//               block finds the reads its range touches by binary search in off[]; each thread derives
+//               its unit-start flag and whether it is a singleton (resolved on the spot), zeroes its
+//               global mark, and the block writes: a 64-bit unit-start mask per wave-tile, its unit and
+//               singleton counts, and ONE integer atomic per (block, read) for the q_span sum
+//               (order-independent, so deterministic).
+// k_scan_blocks: exclusive scan of the per-block unit counts (single block) -> counters[0..1].
+// k_emit_units: one thread per mask word; writes the Unit records in anchor order (deterministic).
+// A single same-address atomic per wave would cap this stage at ~90 atomics/us (measured: 9 ms for
+// 76 M anchors), hence count -> scan -> emit.
 
-__global__ __launch_bounds__(256) void k_prepass(Params par, int64_t n_reads, const int64_t *__restrict__ off,
-                                                 const ulonglong2 *__restrict__ a, float *__restrict__ avgq,
-                                                 Unit *__restrict__ units, unsigned long long *__restrict__ counters,
-                                                 int32_t *__restrict__ f, int32_t *__restrict__ p, int32_t *__restrict__ v,
-                                                 int32_t *__restrict__ tg)
+#define PRE_BLOCK 256
+#define PRE_PER_BLOCK 1024
+#define PRE_WORDS (PRE_PER_BLOCK / 64)
+
+// largest r in [lo, hi] with off[r] <= g   (off is non-decreasing; empty reads are skipped over)
+__device__ __forceinline__ int64_t read_of(const int64_t *__restrict__ off, int64_t lo, int64_t hi, int64_t g)
 {
-	const int lane = threadIdx.x & 63;
-	const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-	const uint64_t maxx = (uint64_t)(int64_t)par.max_dist_x;
+	while (lo < hi) {
+		const int64_t mid = (lo + hi + 1) >> 1;
+		if (off[mid] <= g) lo = mid; else hi = mid - 1;
+	}
+	return lo;
+}
 
-	for (int64_t r = wave0; r < n_reads; r += n_waves) {
-		const int64_t rs = off[r], n = off[r + 1] - rs;
-		uint64_t sum = 0;
-		unsigned long long n_single = 0;
-		for (int64_t t0 = 0; t0 < n; t0 += 64) {
-			const int64_t i = t0 + lane;
-			const bool have = i < n;
-			bool start = false, single = false;
-			if (have) {
-				const ulonglong2 an = a[rs + i];
-				const int span = span_of_hi((uint32_t)(an.y >> 32));
-				start = i == 0 || an.x - a[rs + i - 1].x > maxx;
-				const bool next_starts = i + 1 >= n || a[rs + i + 1].x - an.x > maxx;
-				single = start && next_starts;
-				sum += (uint64_t)span;
-				tg[rs + i] = 0;
-				if (single) { f[rs + i] = span; p[rs + i] = -1; v[rs + i] = span; } // chain.c:251,283-284 with an empty window
-			}
-			const bool emit = start && !single;
-			const uint64_t em = __builtin_amdgcn_ballot_w64(emit);
-			n_single += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(single));
-			if (em) {
-				unsigned long long base = 0;
-				if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)__builtin_popcountll(em));
-				base = readlane_u64(base, 0);
-				if (emit) {
-					Unit u;
-					u.start = rs + i; u.read = (int32_t)r; u.pad = 0;
-					units[base + lanes_below(em)] = u;
-				}
-			}
+__global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_reads, int64_t total,
+                                                       const int64_t *__restrict__ off, const ulonglong2 *__restrict__ a,
+                                                       unsigned long long *__restrict__ sumq, uint64_t *__restrict__ start_mask,
+                                                       uint32_t *__restrict__ block_units, uint32_t *__restrict__ block_singles,
+                                                       int32_t *__restrict__ f, int32_t *__restrict__ p, int32_t *__restrict__ v,
+                                                       int32_t *__restrict__ tg)
+{
+	__shared__ int64_t s_rlo, s_rhi;
+	__shared__ unsigned int s_sum, s_units, s_singles;
+	const int lane = threadIdx.x & 63;
+	const uint64_t maxx = (uint64_t)(int64_t)par.max_dist_x;
+	const int64_t g0 = (int64_t)blockIdx.x * PRE_PER_BLOCK;
+	const int64_t g1 = g0 + PRE_PER_BLOCK < total ? g0 + PRE_PER_BLOCK : total;
+	if (threadIdx.x == 0) {
+		s_rlo = read_of(off, 0, n_reads - 1, g0);
+		s_rhi = read_of(off, 0, n_reads - 1, g1 - 1);
+		s_sum = 0; s_units = 0; s_singles = 0;
+	}
+	__syncthreads();
+	const int64_t rlo = s_rlo, rhi = s_rhi;
+	const bool one_read = rlo == rhi;
+	unsigned int w_sum = 0, w_units = 0, w_singles = 0;
+	for (int64_t gb = g0; gb < g1; gb += PRE_BLOCK) {
+		const int64_t g = gb + threadIdx.x;
+		const bool have = g < g1;
+		bool start = false, single = false;
+		int span = 0;
+		int64_t r = rlo;
+		if (have) {
+			if (!one_read) r = read_of(off, rlo, rhi, g);
+			const int64_t rs = off[r], re = off[r + 1];
+			const ulonglong2 an = a[g];
+			span = span_of_hi((uint32_t)(an.y >> 32));
+			start = g == rs || an.x - a[g - 1].x > maxx;
+			const bool next_starts = g + 1 >= re || a[g + 1].x - an.x > maxx;
+			single = start && next_starts;
+			tg[g] = 0;
+			if (single) { f[g] = span; p[g] = -1; v[g] = span; }   // chain.c:251,283-284 with an empty window
 		}
-		// wave reduction of the per-lane partial sums (chain.c:240)
-		for (int s = 32; s; s >>= 1) sum += __shfl_xor(sum, s, 64);
-		if (lane == 0) {
-			avgq[r] = (float)sum / (float)n;                       // chain.c:241: f32 divide of converted u64 and i64
-			if (n_single) atomicAdd(&counters[1], n_single);
+		// q_span sum (chain.c:240): per block when the block sits inside one read, else per wave when the
+		// wave does, else (the one wave that straddles a read boundary) per lane
+		if (one_read) w_sum += (unsigned int)span;
+		else {
+			const int64_t r_first = (int64_t)readlane_u64((uint64_t)r, 0);
+			if (__builtin_amdgcn_ballot_w64(have && r != r_first) == 0) {
+				int sw = have ? span : 0;
+				for (int d = 32; d; d >>= 1) sw += __shfl_xor(sw, d, 64);
+				if (lane == 0 && sw) atomicAdd(&sumq[r_first], (unsigned long long)sw);
+			} else if (have) atomicAdd(&sumq[r], (unsigned long long)span);
 		}
+		const uint64_t em = __builtin_amdgcn_ballot_w64(start && !single);
+		const uint64_t sm = __builtin_amdgcn_ballot_w64(single);
+		if (lane == 0 && gb + (threadIdx.x & ~63) < g1) start_mask[(gb + (threadIdx.x & ~63)) >> 6] = em;
+		w_units += (unsigned int)__builtin_popcountll(em);
+		w_singles += (unsigned int)__builtin_popcountll(sm);
+	}
+	if (one_read) {
+		for (int d = 32; d; d >>= 1) w_sum += __shfl_xor(w_sum, d, 64);
+		if (lane == 0 && w_sum) atomicAdd(&s_sum, w_sum);
+	}
+	if (lane == 0) { atomicAdd(&s_units, w_units); atomicAdd(&s_singles, w_singles); }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		if (one_read && s_sum) atomicAdd(&sumq[rlo], (unsigned long long)s_sum);
+		block_units[blockIdx.x] = s_units;
+		block_singles[blockIdx.x] = s_singles;
+	}
+}
+
+// in place: block_units[b] <- exclusive prefix sum; counters[0] <- total units, counters[1] <- total singletons
+__global__ __launch_bounds__(1024) void k_scan_blocks(int64_t n_blocks, uint32_t *__restrict__ block_units,
+                                                      const uint32_t *__restrict__ block_singles,
+                                                      unsigned long long *__restrict__ counters)
+{
+	__shared__ unsigned long long part[1024], part_s[1024];
+	const int tid = threadIdx.x;
+	const int64_t per = (n_blocks + 1023) / 1024;
+	const int64_t lo = (int64_t)tid * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+	unsigned long long s = 0, ss = 0;
+	for (int64_t b = lo; b < hi; ++b) { s += block_units[b]; ss += block_singles[b]; }
+	part[tid] = s; part_s[tid] = ss;
+	__syncthreads();
+	if (tid == 0) {
+		unsigned long long acc = 0, acc_s = 0;
+		for (int k = 0; k < 1024; ++k) { const unsigned long long t = part[k]; part[k] = acc; acc += t; acc_s += part_s[k]; }
+		counters[0] = acc; counters[1] = acc_s;
+	}
+	__syncthreads();
+	unsigned long long acc = part[tid];
+	for (int64_t b = lo; b < hi; ++b) { const uint32_t t = block_units[b]; block_units[b] = (uint32_t)acc; acc += t; }
+}
+
+__global__ __launch_bounds__(256) void k_emit_units(int64_t n_reads, int64_t n_words, const int64_t *__restrict__ off,
+                                                    const uint64_t *__restrict__ start_mask,
+                                                    const uint32_t *__restrict__ block_base, Unit *__restrict__ units)
+{
+	const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= n_words) return;
+	uint64_t m = start_mask[w];
+	if (!m) return;
+	const int64_t b = w / PRE_WORDS;
+	uint64_t pos = block_base[b];
+	for (int64_t k = b * PRE_WORDS; k < w; ++k) pos += (uint64_t)__builtin_popcountll(start_mask[k]);
+	int64_t r = read_of(off, 0, n_reads - 1, w << 6);
+	while (m) {
+		const int bit = __builtin_ctzll(m);
+		m &= m - 1;
+		const int64_t g = (w << 6) + bit;
+		while (g >= off[r + 1]) ++r;            // units of one word are in anchor order; reads only move forward
+		Unit u;
+		u.start = g; u.read = (int32_t)r; u.pad = 0;
+		units[pos++] = u;
 	}
 }
 
@@ -180,7 +266,7 @@ __device__ __forceinline__ int pair_score(int sc0, int dd, int dr, int dq, bool 
 template <int RING>
 __global__ __launch_bounds__(64) void k_chain_units(Params par, const int64_t *__restrict__ off,
                                                     const ulonglong2 *__restrict__ a, const int32_t *__restrict__ n_segs_pr,
-                                                    const float *__restrict__ avgq, const Unit *__restrict__ units,
+                                                    const unsigned long long *__restrict__ sumq, const Unit *__restrict__ units,
                                                     const unsigned long long *__restrict__ counters,
                                                     int32_t *f, int32_t *p, int32_t *v, int32_t *tg)
 {
@@ -199,7 +285,7 @@ __global__ __launch_bounds__(64) void k_chain_units(Params par, const int64_t *_
 		const int64_t base = u.start;
 		const int64_t room = re - base;
 		const int rel0 = (int)(base - rs);
-		const double avgd = (double)avgq[u.read];
+		const double avgd = (double)((float)(uint64_t)sumq[u.read] / (float)(int64_t)(re - rs));   // chain.c:241: f32 divide of converted u64 and i64
 		const int n_segs = n_segs_pr ? n_segs_pr[u.read] : par.n_segs;
 		const uint64_t maxx = (uint64_t)(int64_t)par.max_dist_x;
 		const int mdx = par.max_dist_x, mdy = par.max_dist_y, bw = par.bw, max_skip = par.max_skip, is_cdna = par.is_cdna;
@@ -359,20 +445,33 @@ __global__ __launch_bounds__(64) void k_chain_units(Params par, const int64_t *_
 
 // ---------------------------------------------------------------- launchers
 
-hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, const int64_t *d_off, const void *d_a,
-                          float *d_avgq, Unit *d_units, unsigned long long *d_counters,
+hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off, const void *d_a,
+                          unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
                           int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg)
 {
-	if (n_reads <= 0) return hipSuccess;
-	int64_t blocks = (n_reads + 3) / 4;
-	if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
-	hipLaunchKernelGGL(k_prepass, dim3((unsigned)blocks), dim3(256), 0, st, par, n_reads, d_off, (const ulonglong2*)d_a,
-	                   d_avgq, d_units, d_counters, d_f, d_p, d_v, d_tg);
+	hipError_t e = hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st);
+	if (e != hipSuccess || n_reads <= 0 || total <= 0) return e;
+	if ((e = hipMemsetAsync(d_sumq, 0, (size_t)n_reads * sizeof(unsigned long long), st)) != hipSuccess) return e;
+	const int64_t blocks = (total + PRE_PER_BLOCK - 1) / PRE_PER_BLOCK;
+	const int64_t words = (total + 63) / 64;
+	hipLaunchKernelGGL(k_prepass, dim3((unsigned)blocks), dim3(PRE_BLOCK), 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a,
+	                   d_sumq, sc.start_mask, sc.block_units, sc.block_singles, d_f, d_p, d_v, d_tg);
+	hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blocks, sc.block_units, sc.block_singles, d_counters);
+	hipLaunchKernelGGL(k_emit_units, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, n_reads, words, d_off,
+	                   sc.start_mask, sc.block_units, d_units);
 	return hipGetLastError();
 }
 
+size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *blocks_bytes)
+{
+	const size_t words = (size_t)(max_anchors + 63) / 64, blocks = (size_t)(max_anchors + PRE_PER_BLOCK - 1) / PRE_PER_BLOCK;
+	*mask_bytes = (words + 1) * 8;
+	*blocks_bytes = (blocks + 1) * 4;
+	return *mask_bytes + 2 * *blocks_bytes;
+}
+
 hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
-                        const int32_t *d_n_segs, const float *d_avgq, const Unit *d_units,
+                        const int32_t *d_n_segs, const unsigned long long *d_sumq, const Unit *d_units,
                         const unsigned long long *d_counters, int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg)
 {
 	if (max_units <= 0) return hipSuccess;
@@ -383,9 +482,9 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
 	if (blocks > cap) blocks = cap;
 	const ulonglong2 *aa = (const ulonglong2*)d_a;
 	switch (ring) {
-	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), 0, st, par, d_off, aa, d_n_segs, d_avgq, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
-	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), 0, st, par, d_off, aa, d_n_segs, d_avgq, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
-	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), 0, st, par, d_off, aa, d_n_segs, d_avgq, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
+	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), 0, st, par, d_off, aa, d_n_segs, d_sumq, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
+	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), 0, st, par, d_off, aa, d_n_segs, d_sumq, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
+	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), 0, st, par, d_off, aa, d_n_segs, d_sumq, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
 	}
 	return hipGetLastError();
 }
