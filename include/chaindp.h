@@ -126,6 +126,9 @@ int chaindp_get_stats(chaindp_ctx_t *ctx, int64_t st[4]);
 
 /* Kernel tuning knob, mainly for tests: LDS ring capacity in anchors (128, 256 or 512). */
 int chaindp_set_ring(chaindp_ctx_t *ctx, int ring);
+/* force_general != 0 sends every unit through the general (64-bit, f64 gap cost) variant of the DP kernel
+ * instead of the table-driven fast variant; results are identical, this exists for tests. */
+int chaindp_set_variant(chaindp_ctx_t *ctx, int force_general);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     "chaindp_upload", "chaindp_run", "chaindp_sync", "chaindp_download", "chaindp_compact",
     "chaindp_upload_gather", "chaindp_compact_offsets", "chaindp_download_seeds", "chaindp_host_alloc",
     "chaindp_host_free", "chaindp_run_device", "chaindp_set_profiling", "chaindp_get_kernel_ms",
-    "chaindp_get_stats", "chaindp_set_ring", "chaindp_run_full",
+    "chaindp_get_stats", "chaindp_set_ring", "chaindp_run_full", "chaindp_set_variant",
 )
 
 
@@ -66,6 +66,7 @@ def lib():
         L.chaindp_get_kernel_ms.argtypes = [vp, vp, vp, i32]
         L.chaindp_get_stats.argtypes = [vp, vp]
         L.chaindp_set_ring.argtypes = [vp, i32]
+        L.chaindp_set_variant.argtypes = [vp, i32]
         _lib = L
     return _lib
 
@@ -171,6 +172,12 @@ class Device:
     def run_device(self, par, n_reads, total, d_off, d_a, d_n_segs, d_f, d_p, d_v, stream=0):
         self._check(self._lib.chaindp_run_device(self._ctx, C.byref(par), n_reads, total, d_off, d_a, d_n_segs or None,
                                                  d_f, d_p, d_v, stream or None))
+
+    def set_ring(self, ring):
+        self._check(self._lib.chaindp_set_ring(self._ctx, ring))
+
+    def set_variant(self, force_general):
+        self._check(self._lib.chaindp_set_variant(self._ctx, int(bool(force_general))))
 
     # -- measurement
     def set_profiling(self, on=True):

@@ -22,7 +22,7 @@ struct chaindp_ctx {
 	int device = -1;
 	hipStream_t stream = nullptr;
 	int64_t cap_anchors = 0, cap_reads = 0;
-	int ring = 256;
+	int ring = 128;
 	// resident batch
 	int64_t n_reads = 0, total = 0, n_seeds = 0;
 	bool has_n_segs = false, ran = false;
@@ -36,6 +36,9 @@ struct chaindp_ctx {
 	Unit *d_units = nullptr;
 	unsigned long long *d_counters = nullptr;
 	chaindp::PrepassScratch pre = {nullptr, nullptr, nullptr};
+	int16_t *d_lut = nullptr;
+	size_t lut_bytes = 0;
+	bool use_lut = true;
 	// compaction (allocated on first use)
 	int32_t *d_first_child = nullptr, *d_id = nullptr;
 	int64_t *d_seeds_off = nullptr;
@@ -97,7 +100,7 @@ extern "C" void chaindp_destroy(chaindp_ctx_t *ctx)
 	if (ctx->stream) hipStreamSynchronize(ctx->stream);
 	for (auto &es : ctx->pending) for (int k = 0; k < es.n; ++k) hipEventDestroy(es.e[k]);
 	void *bufs[] = {ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_sumq, ctx->d_units,
-	                ctx->d_counters, ctx->pre.start_mask, ctx->pre.block_units, ctx->pre.block_singles, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
+	                ctx->d_counters, ctx->pre.start_mask, ctx->pre.block_units, ctx->pre.block_singles, ctx->d_lut, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
 	for (void *b : bufs) if (b) hipFree(b);
 	if (ctx->stream) hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -146,6 +149,13 @@ extern "C" int chaindp_set_ring(chaindp_ctx_t *ctx, int ring)
 	return CHAINDP_OK;
 }
 
+extern "C" int chaindp_set_variant(chaindp_ctx_t *ctx, int force_general)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	ctx->use_lut = force_general == 0;
+	return CHAINDP_OK;
+}
+
 extern "C" int chaindp_set_profiling(chaindp_ctx_t *ctx, int on)
 {
 	if (!ctx) return CHAINDP_ERR_ARG;
@@ -175,8 +185,24 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[0], st));
 	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, d_f, d_p, d_v, ctx->d_tg));
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[1], st));
-	HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, total / 2, d_off, d_a, d_n_segs, ctx->d_sumq, ctx->d_units, ctx->d_counters,
-	                                   d_f, d_p, d_v, ctx->d_tg));
+	// per-read gap-cost table for the fast variant (skipped when the table would not apply)
+	int16_t *lut = nullptr;
+	int lut_stride = 0;
+	if (ctx->use_lut && !q.is_cdna && q.bw <= CHAINDP_LUT_MAX_BW && n_reads > 0) {
+		lut_stride = (q.bw + 1 + 7) & ~7;
+		const size_t need = (size_t)n_reads * lut_stride * sizeof(int16_t);
+		if (need > ctx->lut_bytes) {
+			HIP_TRY(ctx, hipStreamSynchronize(st));
+			if (ctx->d_lut) HIP_TRY(ctx, hipFree(ctx->d_lut));
+			ctx->d_lut = nullptr; ctx->lut_bytes = 0;
+			HIP_TRY(ctx, hipMalloc((void**)&ctx->d_lut, need));
+			ctx->lut_bytes = need;
+		}
+		lut = ctx->d_lut;
+		HIP_TRY(ctx, chaindp::launch_lut(st, q, n_reads, d_off, ctx->d_sumq, lut_stride, lut));
+	}
+	HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, total / 2, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_units,
+	                                   ctx->d_counters, d_f, d_p, d_v, ctx->d_tg));
 	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[2], st)); ctx->pending.push_back(es); }
 	ctx->stats[2] = total; ctx->stats[3] = n_reads;
 	return CHAINDP_OK;

@@ -104,6 +104,10 @@ __device__ __forceinline__ void wave_global_fence()
 
 // ---------------------------------------------------------------- field access (mmpriv.h:21-22, chain.c:250)
 
+// sumq[r] holds the read's q_span sum (< 2^40); its top bit records "some anchor of the read carries a
+// non-zero segment id", which sends the read's units to the general variant of the DP kernel.
+#define SUMQ_SEG_FLAG (1ull << 63)
+
 __device__ __forceinline__ int span_of_hi(uint32_t yhi) { return (int)(yhi & 0xffu); }        // (y>>32)&0xff
 __device__ __forceinline__ int seg_of_hi(uint32_t yhi) { return (int)((yhi >> 16) & 0xffu); } // (y>>48)&0xff
 
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_rea
 			const int64_t rs = off[r], re = off[r + 1];
 			const ulonglong2 an = a[g];
 			span = span_of_hi((uint32_t)(an.y >> 32));
+			if (seg_of_hi((uint32_t)(an.y >> 32)) != 0) atomicOr(&sumq[r], SUMQ_SEG_FLAG);   // rare: multi-segment reads only
 			start = g == rs || an.x - a[g - 1].x > maxx;
 			const bool next_starts = g + 1 >= re || a[g + 1].x - an.x > maxx;
 			single = start && next_starts;
@@ -248,6 +253,29 @@ __global__ __launch_bounds__(256) void k_emit_units(int64_t n_reads, int64_t n_w
 	}
 }
 
+// ---------------------------------------------------------------- K0b: per-read gap-cost table
+// For a pair of anchors of the same segment in a non-cDNA run the gap cost depends only on
+// dd = |dr - dq| <= bw and on the read's avg_qspan (chain.c:264,272):
+//     cost(dd) = (int)(dd * .01 * avg_qspan) + (ilog2(dd) >> 1)
+// so it is tabulated once per read (bw+1 entries, stored negated as int16) with exactly the
+// reference's f32/f64 operations, and the hot loop does an LDS lookup instead of f64 arithmetic.
+__global__ __launch_bounds__(256) void k_build_lut(Params par, int64_t n_reads, const int64_t *__restrict__ off,
+                                                   const unsigned long long *__restrict__ sumq, int lut_stride,
+                                                   int16_t *__restrict__ lut)
+{
+	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+		const int64_t n = off[r + 1] - off[r];
+		if (n <= 0) continue;
+		const float avg = (float)(uint64_t)(sumq[r] & ~SUMQ_SEG_FLAG) / (float)n;   // chain.c:241
+		const double avgd = (double)avg;
+		for (int dd = threadIdx.x; dd <= par.bw; dd += blockDim.x) {
+			const int lg = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
+			const int lin = (int)((double)dd * .01 * avgd);
+			lut[r * lut_stride + dd] = (int16_t)(-(lin + (lg >> 1)));
+		}
+	}
+}
+
 // ---------------------------------------------------------------- K1: chain DP, one wave per unit
 
 // chain.c:264-272 for one pair; sc0 = min(dq, dr, q_span)
@@ -263,183 +291,279 @@ __device__ __forceinline__ int pair_score(int sc0, int dd, int dr, int dq, bool 
 	return sc0 - (lin + (lg >> 1));
 }
 
+__device__ __forceinline__ uint32_t absdiff_u32(uint32_t x, uint32_t y)
+{
+	uint32_t d;
+	asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(x), "v"(y));
+	return d;
+}
+
+// Per-unit constants and the LDS carve-up.  Ring entry k (16 B): x.lo, qpos, f, p (unit-relative);
+// side arrays: mark tag t[], v[], and (general variant only) x.hi[], y.hi[]; then the read's cost table.
+struct UnitCtx {
+	const ulonglong2 *a;
+	int32_t *f, *p, *v, *tg;
+	uint32_t *s_w;          // ring entries, 4 dwords each
+	int *s_t, *s_v;
+	uint32_t *s_xhi, *s_yhi;
+	const int16_t *s_lut;
+	int64_t base;
+	uint64_t maxx;
+	double avgd;
+	int rel0, lane;
+	int mdx, mdy, mdq, bw, max_skip, is_cdna;
+	bool seg_rule;
+};
+
+// One chunk of 64 predecessors of anchor i (unit-relative), j = i-1-kb0-lane.
+//   GEN  = false: fast variant -- every anchor of the read has segment id 0, not cDNA, cost table in LDS,
+//                 and max_dist_x * RING < 2^32, so that all in-ring differences are exact in 32 bits.
+//   GEN  = true : the reference's general formulas in 64-bit arithmetic.
+//   DEEP = true : the predecessors are older than the ring and come from global memory (always general math).
+// Returns true when the scan for anchor i is complete (break taken, or window / unit exhausted).
+template <int RING, bool GEN, bool DEEP>
+__device__ __forceinline__ bool scan_chunk(const UnitCtx &c, const ulonglong2 &an, int ii, int i, int kb0, int qi, int span,
+                                           int &max_f, int &max_j, int &n_skip)
+{
+	constexpr int MASK = RING - 1, DEPTH = RING - 64;
+	const int lane = c.lane;
+	const int tag = i + 1;
+	const bool inr = kb0 + lane < i;
+	const int j = i - 1 - kb0 - lane;
+	const int slot = j & MASK;
+	int fj = 0, pj = -1, sc;
+	bool live, ok;
+	if constexpr (!GEN && !DEEP) {
+		const uint32_t xi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)an.x, ii);
+		const uint4 e = *(const uint4*)(c.s_w + 4 * slot);
+		const uint32_t dr = xi - e.x;                               // exact: |x_i - x_j| < max_dist_x * RING < 2^32
+		const int dq = (int)((uint32_t)qi - e.y);
+		fj = (int)e.z; pj = (int)e.w;
+		live = inr && dr <= (uint32_t)c.maxx;                       // chain.c:252 (window) per lane
+		const uint32_t dd = absdiff_u32(dr, (uint32_t)dq);
+		ok = live && dr != 0 && (uint32_t)(dq - 1) < (uint32_t)c.mdq && dd <= (uint32_t)c.bw;   // chain.c:257-260, same segment
+		int sc0 = dq < (int)dr ? dq : (int)dr;
+		sc0 = sc0 > span ? span : sc0;                              // chain.c:262-263
+		const uint32_t di = dd < (uint32_t)c.bw ? dd : (uint32_t)c.bw;
+		sc = sc0 + fj + (int)c.s_lut[di];                           // chain.c:272-273 via the table
+	} else {
+		const uint64_t ri = readlane_u64(an.x, ii);
+		const uint32_t yhi_i = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(an.y >> 32), ii);
+		const int sidi = seg_of_hi(yhi_i);
+		uint64_t xj = 0;
+		int qj = 0;
+		uint32_t yhj = 0;
+		if constexpr (!DEEP) {
+			const uint4 e = *(const uint4*)(c.s_w + 4 * slot);
+			xj = (uint64_t)c.s_xhi[slot] << 32 | e.x; qj = (int)e.y; fj = (int)e.z; pj = (int)e.w; yhj = c.s_yhi[slot];
+		} else {
+			wave_global_fence();
+			if (inr) {
+				const ulonglong2 aj = c.a[c.base + j];
+				xj = aj.x; qj = (int)(uint32_t)aj.y; yhj = (uint32_t)(aj.y >> 32);
+				fj = c.f[c.base + j];
+				pj = c.p[c.base + j];
+				pj = pj < 0 ? -1 : pj - c.rel0;                     // stored read-relative
+			}
+		}
+		const uint64_t d64 = ri - xj;
+		live = inr && d64 <= c.maxx;                                // chain.c:252
+		const int dr = (int)d64;
+		const int dq = (int)((uint32_t)qi - (uint32_t)qj);
+		const bool same = seg_of_hi(yhj) == sidi;
+		const int dd = dr > dq ? dr - dq : dq - dr;
+		ok = live;
+		ok = ok && !((same && dr == 0) || dq <= 0);                 // chain.c:257
+		ok = ok && !((same && dq > c.mdy) || dq > c.mdx);           // chain.c:258
+		ok = ok && !(same && dd > c.bw);                            // chain.c:260
+		ok = ok && !(c.seg_rule && same && dr > c.mdy);             // chain.c:261
+		int sc0 = dq < dr ? dq : dr;
+		sc0 = sc0 > span ? span : sc0;
+		sc = pair_score(sc0, dd, dr, dq, same, c.is_cdna, c.avgd) + fj;   // chain.c:264-273
+	}
+	sc = ok ? sc : INT_MIN;
+
+	// marks of every filter-passing lane first (chain.c:281), then each lane reads its own.  A target still
+	// in the ring is marked in LDS, an older one in the global mark array.
+	const int lo_near = i - DEPTH;
+	if (ok && pj >= (lo_near > 0 ? lo_near : 0)) c.s_t[pj & MASK] = tag;
+	if (lo_near > 0) {
+		if (ok && pj >= 0 && pj < lo_near) c.tg[c.base + pj] = tag;
+	}
+	int tj = 0;
+	if constexpr (!DEEP) {
+		wave_mem_fence();
+		tj = c.s_t[slot];
+	} else {
+		wave_global_fence();
+		if (inr) tj = c.tg[c.base + j];
+	}
+
+	// new running max? strictly greater than everything before it (chain.c:274)
+	const int incl = wave_scan_max(sc);
+	int excl = wave_shift_up1(incl, max_f);
+	excl = excl > max_f ? excl : max_f;
+	const bool isA = ok && sc > excl;
+	const bool isB = ok && !isA && tj == tag;                       // chain.c:277
+	const uint64_t A = __builtin_amdgcn_ballot_w64(isA);
+	const uint64_t B = __builtin_amdgcn_ballot_w64(isB);
+	const bool all_live = __builtin_amdgcn_ballot_w64(live) == ~0ull;
+
+	// n_skip walk (chain.c:276,278): A lanes x -> max(x-1,0), B lanes x -> x+1, break when > max_skip
+	int kbrk = -1;
+	if (B == 0) {
+		n_skip -= __builtin_popcountll(A);
+		n_skip = n_skip < 0 ? 0 : n_skip;
+	} else if ((A & ~((B & (0 - B)) - 1)) == 0) {                   // every A lane precedes every B lane
+		int x = n_skip - __builtin_popcountll(A);
+		x = x < 0 ? 0 : x;
+		int need = c.max_skip - x + 1;
+		need = need < 1 ? 1 : need;
+		const int cb = __builtin_popcountll(B);
+		if (cb >= need) {
+			const uint64_t m = __builtin_amdgcn_ballot_w64(isB && lanes_below(B) == need - 1);
+			kbrk = __builtin_ctzll(m);
+		} else n_skip = x + cb;
+	} else {                                                         // general: clamped walk via prefix min
+		const int S = n_skip + lanes_below(B) + (int)isB - lanes_below(A) - (int)isA;
+		const int M = wave_scan_min(S);
+		const int x = S - (M < 0 ? M : 0);
+		const uint64_t m = __builtin_amdgcn_ballot_w64(isB && x > c.max_skip);
+		if (m) kbrk = __builtin_ctzll(m);
+		else n_skip = __builtin_amdgcn_readlane(x, 63);
+	}
+	// the last A lane before the break holds the final running max and its j
+	const uint64_t Ap = kbrk >= 0 ? (A & ((1ull << kbrk) - 1)) : A;
+	if (Ap) {
+		const int ka = 63 - __builtin_clzll(Ap);
+		max_f = __builtin_amdgcn_readlane(sc, ka);
+		max_j = i - 1 - kb0 - ka;
+	}
+	return kbrk >= 0 || !all_live;
+}
+
+template <int RING, bool GEN>
+__device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
+{
+	constexpr int MASK = RING - 1, DEPTH = RING - 64;
+	const int lane = c.lane;
+	uint64_t x_carry = 0;
+	for (int tile0 = 0;; tile0 += 64) {
+		const int64_t gi = c.base + tile0 + lane;
+		const bool have = tile0 + lane < room;
+		ulonglong2 an = make_ulonglong2(0, 0);
+		if (have) an = c.a[gi];
+		// the unit ends at the first gap > max_dist_x (or at the end of the read)
+		uint64_t xp;
+		{
+			const uint32_t lo = (uint32_t)wave_shift_up1((int)(uint32_t)an.x, (int)(uint32_t)x_carry);
+			const uint32_t hi = (uint32_t)wave_shift_up1((int)(uint32_t)(an.x >> 32), (int)(uint32_t)(x_carry >> 32));
+			xp = (uint64_t)hi << 32 | lo;
+		}
+		const bool stop = !have || ((tile0 + lane) > 0 && an.x - xp > c.maxx);
+		const uint64_t stop_m = __builtin_amdgcn_ballot_w64(stop);
+		const int cnt = stop_m ? __builtin_ctzll(stop_m) : 64;
+		if (cnt == 0) break;
+		x_carry = readlane_u64(an.x, 63);
+		const int my_slot = (tile0 + lane) & MASK;
+		wave_mem_fence();
+		if (lane < cnt) {
+			*(uint2*)(c.s_w + 4 * my_slot) = make_uint2((uint32_t)an.x, (uint32_t)an.y);
+			if constexpr (GEN) { c.s_xhi[my_slot] = (uint32_t)(an.x >> 32); c.s_yhi[my_slot] = (uint32_t)(an.y >> 32); }
+		}
+		wave_mem_fence();
+
+		// v[i] = max(v[max_j], f[i]) (chain.c:284) is off the recurrence's critical path: the read of v[max_j]
+		// is issued at the end of step i and consumed one step later.
+		int pend_slot = -1, pend_mf = 0, pend_vj = INT_MIN;
+		for (int ii = 0; ii < cnt; ++ii) {
+			const int i = tile0 + ii;                          // unit-relative index of the anchor being scored
+			const int qi = __builtin_amdgcn_readlane((int)(uint32_t)an.y, ii);
+			const int span = span_of_hi((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(an.y >> 32), ii));
+			int max_f = span, max_j = -1, n_skip = 0;
+			for (int kb0 = 0; kb0 < i; kb0 += 64) {
+				bool done;
+				if (kb0 + 64 <= DEPTH) done = scan_chunk<RING, GEN, false>(c, an, ii, i, kb0, qi, span, max_f, max_j, n_skip);
+				else done = scan_chunk<RING, true, true>(c, an, ii, i, kb0, qi, span, max_f, max_j, n_skip);
+				if (done) break;
+			}
+			// epilogue (chain.c:283-284)
+			wave_mem_fence();
+			if (pend_slot >= 0) {
+				const int vprev = pend_vj > pend_mf ? pend_vj : pend_mf;
+				if (lane == 0) c.s_v[pend_slot] = vprev;
+			}
+			if (lane == 0) *(int2*)(c.s_w + 4 * (i & MASK) + 2) = make_int2(max_f, max_j);
+			wave_mem_fence();
+			pend_slot = i & MASK; pend_mf = max_f; pend_vj = INT_MIN;
+			if (max_j >= 0) {
+				if (i - max_j <= DEPTH) pend_vj = c.s_v[max_j & MASK];
+				else { wave_global_fence(); pend_vj = c.v[c.base + max_j]; }
+			}
+		}
+		wave_mem_fence();
+		{
+			const int vprev = pend_vj > pend_mf ? pend_vj : pend_mf;
+			if (lane == 0) c.s_v[pend_slot] = vprev;
+		}
+		wave_mem_fence();
+		if (lane < cnt) {
+			const int2 fp = *(const int2*)(c.s_w + 4 * my_slot + 2);
+			c.f[gi] = fp.x;
+			c.p[gi] = fp.y < 0 ? -1 : fp.y + c.rel0;
+			c.v[gi] = c.s_v[my_slot];
+		}
+		if (cnt < 64) break;
+	}
+}
+
 template <int RING>
 __global__ __launch_bounds__(64) void k_chain_units(Params par, const int64_t *__restrict__ off,
                                                     const ulonglong2 *__restrict__ a, const int32_t *__restrict__ n_segs_pr,
-                                                    const unsigned long long *__restrict__ sumq, const Unit *__restrict__ units,
+                                                    const unsigned long long *__restrict__ sumq,
+                                                    const int16_t *__restrict__ lut, int lut_stride,
+                                                    const Unit *__restrict__ units,
                                                     const unsigned long long *__restrict__ counters,
                                                     int32_t *f, int32_t *p, int32_t *v, int32_t *tg)
 {
-	constexpr int MASK = RING - 1;
-	constexpr int DEPTH = RING - 64;        // tiles overwrite 64 slots at once, so only RING-64 predecessors are guaranteed resident
-	static_assert((RING & MASK) == 0 && RING >= 128, "RING must be a power of two >= 128");
-	__shared__ uint4 s_a[RING];             // x.lo, x.hi, qpos, y.hi
-	__shared__ int2 s_fp[RING];             // f, p (unit-relative)
-	__shared__ int s_t[RING];               // mark tag (chain.c's t[])
-	__shared__ int s_v[RING];
-
+	static_assert((RING & (RING - 1)) == 0 && RING >= 128, "RING must be a power of two >= 128");
+	extern __shared__ uint4 smem[];
+	UnitCtx c;
+	c.a = a; c.f = f; c.p = p; c.v = v; c.tg = tg;
+	c.s_w = (uint32_t*)smem;
+	c.s_t = (int*)(c.s_w + 4 * RING);
+	c.s_v = c.s_t + RING;
+	c.s_xhi = (uint32_t*)(c.s_v + RING);
+	c.s_yhi = c.s_xhi + RING;
+	int16_t *s_lut = (int16_t*)(c.s_yhi + RING);
+	c.s_lut = s_lut;
+	c.lane = threadIdx.x;
+	c.maxx = (uint64_t)(int64_t)par.max_dist_x;
+	c.mdx = par.max_dist_x; c.mdy = par.max_dist_y; c.bw = par.bw; c.max_skip = par.max_skip; c.is_cdna = par.is_cdna;
+	c.mdq = par.max_dist_x < par.max_dist_y ? par.max_dist_x : par.max_dist_y;   // dq > max_dist_y || dq > max_dist_x (same segment)
+	const bool x32_ok = (uint64_t)(int64_t)par.max_dist_x * (uint64_t)RING < (1ull << 32);
 	const int lane = threadIdx.x;
+
 	for (int64_t ub = blockIdx.x; ub < (int64_t)counters[0]; ub += gridDim.x) {
 		const Unit u = units[ub];
 		const int64_t rs = off[u.read], re = off[u.read + 1];
-		const int64_t base = u.start;
-		const int64_t room = re - base;
-		const int rel0 = (int)(base - rs);
-		const double avgd = (double)((float)(uint64_t)sumq[u.read] / (float)(int64_t)(re - rs));   // chain.c:241: f32 divide of converted u64 and i64
+		const unsigned long long sq = sumq[u.read];
 		const int n_segs = n_segs_pr ? n_segs_pr[u.read] : par.n_segs;
-		const uint64_t maxx = (uint64_t)(int64_t)par.max_dist_x;
-		const int mdx = par.max_dist_x, mdy = par.max_dist_y, bw = par.bw, max_skip = par.max_skip, is_cdna = par.is_cdna;
-		const bool seg_rule = n_segs > 1 && !is_cdna;        // chain.c:261
+		c.base = u.start;
+		c.rel0 = (int)(u.start - rs);
+		c.avgd = (double)((float)(uint64_t)(sq & ~SUMQ_SEG_FLAG) / (float)(int64_t)(re - rs));   // chain.c:241: f32 divide of converted u64 and i64
+		c.seg_rule = n_segs > 1 && !par.is_cdna;                   // chain.c:261
+		const bool general = par.is_cdna || n_segs > 1 || (sq & SUMQ_SEG_FLAG) || lut == nullptr || !x32_ok;
 
 		wave_mem_fence();
-		for (int k = lane; k < RING; k += 64) s_t[k] = 0;
-		uint64_t x_carry = 0;
-
-		for (int tile0 = 0;; tile0 += 64) {
-			const int64_t gi = base + tile0 + lane;
-			const bool have = tile0 + lane < room;
-			ulonglong2 an = make_ulonglong2(0, 0);
-			if (have) an = a[gi];
-			// the unit ends at the first gap > max_dist_x (or at the end of the read)
-			uint64_t xp;
-			{
-				const uint32_t lo = (uint32_t)wave_shift_up1((int)(uint32_t)an.x, (int)(uint32_t)x_carry);
-				const uint32_t hi = (uint32_t)wave_shift_up1((int)(uint32_t)(an.x >> 32), (int)(uint32_t)(x_carry >> 32));
-				xp = (uint64_t)hi << 32 | lo;
-			}
-			const bool stop = !have || ((tile0 + lane) > 0 && an.x - xp > maxx);
-			const uint64_t stop_m = __builtin_amdgcn_ballot_w64(stop);
-			const int cnt = stop_m ? __builtin_ctzll(stop_m) : 64;
-			if (cnt == 0) break;
-			x_carry = readlane_u64(an.x, 63);
-			const uint32_t my_yhi = (uint32_t)(an.y >> 32);
-			wave_mem_fence();
-			if (lane < cnt)
-				s_a[(tile0 + lane) & MASK] = make_uint4((uint32_t)an.x, (uint32_t)(an.x >> 32), (uint32_t)an.y, my_yhi);
-			wave_mem_fence();
-
-			int fo = 0, po = -1, vo = 0;
-			for (int ii = 0; ii < cnt; ++ii) {
-				const int i = tile0 + ii;                      // unit-relative index of the anchor being scored
-				const uint64_t ri = readlane_u64(an.x, ii);
-				const int qi = __builtin_amdgcn_readlane((int)(uint32_t)an.y, ii);
-				const uint32_t yhi_i = (uint32_t)__builtin_amdgcn_readlane((int)my_yhi, ii);
-				const int span = span_of_hi(yhi_i), sidi = seg_of_hi(yhi_i);
-				const int tag = i + 1;
-				int max_f = span, max_j = -1, n_skip = 0;
-
-				for (int kb0 = 0; kb0 < i; kb0 += 64) {
-					const bool deep = kb0 + 64 > DEPTH;        // wave-uniform
-					const int k = kb0 + lane;
-					const bool inr = k < i;
-					const int j = i - 1 - k;
-					const int slot = j & MASK;
-					uint64_t xj = 0;
-					int qj = 0, fj = 0, pj = -1;
-					uint32_t yhj = 0;
-					if (!deep) {
-						const uint4 aj = s_a[slot];
-						const int2 fp = s_fp[slot];
-						xj = (uint64_t)aj.y << 32 | aj.x; qj = (int)aj.z; yhj = aj.w; fj = fp.x; pj = fp.y;
-					} else {
-						wave_global_fence();
-						if (inr) {
-							const ulonglong2 aj = a[base + j];
-							xj = aj.x; qj = (int)(uint32_t)aj.y; yhj = (uint32_t)(aj.y >> 32);
-							fj = f[base + j];
-							pj = p[base + j];
-							pj = pj < 0 ? -1 : pj - rel0;          // stored read-relative
-						}
-					}
-					const uint64_t d64 = ri - xj;
-					const bool live = inr && d64 <= maxx;          // chain.c:252 (window) per lane
-					const int dr = (int)d64;
-					const int dq = (int)((uint32_t)qi - (uint32_t)qj);
-					const bool same = seg_of_hi(yhj) == sidi;
-					const int dd = dr > dq ? dr - dq : dq - dr;
-					bool ok = live;
-					ok = ok && !((same && dr == 0) || dq <= 0);                    // chain.c:257
-					ok = ok && !((same && dq > mdy) || dq > mdx);                  // chain.c:258
-					ok = ok && !(same && dd > bw);                                 // chain.c:260
-					ok = ok && !(seg_rule && same && dr > mdy);                    // chain.c:261
-					int sc0 = dq < dr ? dq : dr;
-					sc0 = sc0 > span ? span : sc0;                                 // chain.c:262-263
-					int sc = pair_score(sc0, dd, dr, dq, same, is_cdna, avgd) + fj; // chain.c:264-273
-					sc = ok ? sc : INT_MIN;
-
-					// marks of every filter-passing lane first (chain.c:281), then each lane reads its own
-					if (ok && pj >= 0) {
-						if (i - pj <= DEPTH) s_t[pj & MASK] = tag;
-						else tg[base + pj] = tag;
-					}
-					int tj = 0;
-					if (!deep) {
-						wave_mem_fence();
-						tj = s_t[slot];
-					} else {
-						wave_global_fence();
-						if (inr) tj = tg[base + j];
-					}
-
-					// new running max? strictly greater than everything before it (chain.c:274)
-					const int incl = wave_scan_max(sc);
-					int excl = wave_shift_up1(incl, max_f);
-					excl = excl > max_f ? excl : max_f;
-					const bool isA = ok && sc > excl;
-					const bool isB = ok && !isA && tj == tag;                      // chain.c:277
-					const uint64_t A = __builtin_amdgcn_ballot_w64(isA);
-					const uint64_t B = __builtin_amdgcn_ballot_w64(isB);
-					const bool all_live = __builtin_amdgcn_ballot_w64(live) == ~0ull;
-
-					// n_skip walk (chain.c:276,278): A lanes x -> max(x-1,0), B lanes x -> x+1, break when > max_skip
-					int kbrk = -1;
-					if (B == 0) {
-						n_skip -= __builtin_popcountll(A);
-						n_skip = n_skip < 0 ? 0 : n_skip;
-					} else if ((A & ~((B & (0 - B)) - 1)) == 0) {                  // every A lane precedes every B lane
-						int x = n_skip - __builtin_popcountll(A);
-						x = x < 0 ? 0 : x;
-						int need = max_skip - x + 1;
-						need = need < 1 ? 1 : need;
-						const int cb = __builtin_popcountll(B);
-						if (cb >= need) {
-							const uint64_t m = __builtin_amdgcn_ballot_w64(isB && lanes_below(B) == need - 1);
-							kbrk = __builtin_ctzll(m);
-						} else n_skip = x + cb;
-					} else {                                                        // general: clamped walk via prefix min
-						const int S = n_skip + lanes_below(B) + (int)isB - lanes_below(A) - (int)isA;
-						const int M = wave_scan_min(S);
-						const int x = S - (M < 0 ? M : 0);
-						const uint64_t m = __builtin_amdgcn_ballot_w64(isB && x > max_skip);
-						if (m) kbrk = __builtin_ctzll(m);
-						else n_skip = __builtin_amdgcn_readlane(x, 63);
-					}
-					// the last A lane before the break holds the final running max and its j
-					const uint64_t Ap = kbrk >= 0 ? (A & ((1ull << kbrk) - 1)) : A;
-					if (Ap) {
-						const int ka = 63 - __builtin_clzll(Ap);
-						max_f = __builtin_amdgcn_readlane(sc, ka);
-						max_j = i - 1 - kb0 - ka;
-					}
-					if (kbrk >= 0 || !all_live) break;
-				}
-
-				// chain.c:283-284
-				int vi = max_f;
-				if (max_j >= 0) {
-					int vj;
-					if (i - max_j <= DEPTH) { wave_mem_fence(); vj = s_v[max_j & MASK]; }
-					else { wave_global_fence(); vj = v[base + max_j]; }
-					vi = vj > max_f ? vj : max_f;
-				}
-				if (lane == ii) { fo = max_f; po = max_j < 0 ? -1 : max_j + rel0; vo = vi; }
-				wave_mem_fence();
-				if (lane == 0) { s_fp[i & MASK] = make_int2(max_f, max_j); s_v[i & MASK] = vi; }
-				wave_mem_fence();
-			}
-			if (lane < cnt) { f[gi] = fo; p[gi] = po; v[gi] = vo; }
-			if (cnt < 64) break;
+		for (int k = lane; k < RING; k += 64) c.s_t[k] = 0;
+		if (!general) {
+			const uint4 *src = (const uint4*)(lut + (int64_t)u.read * lut_stride);   // lut_stride is a multiple of 8 entries (16 B)
+			for (int k = lane; k * 8 < lut_stride; k += 64) ((uint4*)s_lut)[k] = src[k];
 		}
+		wave_mem_fence();
+		if (general) run_unit<RING, true>(c, re - u.start);
+		else run_unit<RING, false>(c, re - u.start);
 	}
 }
 
@@ -470,9 +594,24 @@ size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *bl
 	return *mask_bytes + 2 * *blocks_bytes;
 }
 
+size_t chain_lds_bytes(int ring, int lut_stride)
+{
+	return (size_t)ring * 32 + (size_t)lut_stride * 2;
+}
+
+hipError_t launch_lut(hipStream_t st, const Params &par, int64_t n_reads, const int64_t *d_off,
+                      const unsigned long long *d_sumq, int lut_stride, int16_t *d_lut)
+{
+	if (n_reads <= 0) return hipSuccess;
+	int64_t blocks = n_reads < 65536 ? n_reads : 65536;
+	hipLaunchKernelGGL(k_build_lut, dim3((unsigned)blocks), dim3(256), 0, st, par, n_reads, d_off, d_sumq, lut_stride, d_lut);
+	return hipGetLastError();
+}
+
 hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
-                        const int32_t *d_n_segs, const unsigned long long *d_sumq, const Unit *d_units,
-                        const unsigned long long *d_counters, int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg)
+                        const int32_t *d_n_segs, const unsigned long long *d_sumq, const int16_t *d_lut, int lut_stride,
+                        const Unit *d_units, const unsigned long long *d_counters,
+                        int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg)
 {
 	if (max_units <= 0) return hipSuccess;
 	// The number of units is only known on the device (counters[0]); the grid is sized for the upper
@@ -481,10 +620,11 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
 	const int64_t cap = 256LL * 32 * 16;
 	if (blocks > cap) blocks = cap;
 	const ulonglong2 *aa = (const ulonglong2*)d_a;
+	const size_t lds = chain_lds_bytes(ring, d_lut ? lut_stride : 0);
 	switch (ring) {
-	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), 0, st, par, d_off, aa, d_n_segs, d_sumq, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
-	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), 0, st, par, d_off, aa, d_n_segs, d_sumq, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
-	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), 0, st, par, d_off, aa, d_n_segs, d_sumq, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
+	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
+	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
+	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
 	}
 	return hipGetLastError();
 }

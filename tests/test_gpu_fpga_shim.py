@@ -1,0 +1,65 @@
+"""GPU tier: the reference's driver ABI (fpga.h) served by the GPU: anchor packets in, result packets
+out, from several producer threads, checked against the oracle's new_seed[] byte for byte."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from minimap2_chaindp_amd import anchorgen as ag, fpga, params as P
+
+pytestmark = pytest.mark.gpu
+
+
+def test_packets_through_driver_abi_match_oracle():
+    par = P.preset("ava-ont")
+    n_reads, per_packet, n_threads = 200, 8, 4                         # 8 reads per packet: map.c:423
+    off, a = ag.generate("ava-ont", n_reads=n_reads, seed=31)
+    reads = [(r, a[off[r]:off[r + 1]]) for r in range(n_reads)]
+    packets = [reads[k:k + per_packet] for k in range(0, n_reads, per_packet)]
+    with fpga.Driver(bw=par.bw, is_cdna=par.is_cdna, max_skip=par.max_skip, min_sc=par.min_sc,
+                     max_packets_per_batch=7) as drv:
+        def producer(tid):
+            for k in range(tid, len(packets), n_threads):
+                pkt = fpga.build_task_packet(packets[k], gap_ref=par.max_dist_x, gap_qry=par.max_dist_y, tid=tid)
+                assert drv.submit(pkt, tid) == 0
+        ths = [threading.Thread(target=producer, args=(t,)) for t in range(n_threads)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        results = drv.wait_results(len(packets))
+        st = drv.stats()
+    assert st["packets"] == len(packets) and st["reads"] == n_reads and st["anchors"] == int(off[-1]) and st["err_reads"] == 0
+    seen = {}
+    for raw in results:
+        for read_id, err, seeds in fpga.parse_result_packet(raw):
+            assert err == 0 and read_id not in seen
+            seen[read_id] = seeds
+    assert sorted(seen) == list(range(n_reads))                        # matched by read_id, any order (map.c:930)
+    for r in range(n_reads):
+        ar = np.ascontiguousarray(a[off[r]:off[r + 1]])
+        f, p, v, _ = ol.oracle_fpv(par, ar)
+        exp = ol.oracle_compact(par, ar, f, p, v)
+        assert seen[r].tobytes() == exp.tobytes(), r
+
+
+def test_minimizer_packets_get_err_flag_and_mixed_gaps_are_grouped():
+    par = P.preset("map-ont")
+    off, a = ag.generate("map-ont", n_reads=6, seed=5, read_len=2000)
+    with fpga.Driver(bw=par.bw, is_cdna=0, max_skip=par.max_skip, min_sc=par.min_sc) as drv:
+        # the reference's own packet type (minimizers, type 3): answered with err_flag=1, header only
+        drv.submit(fpga.build_task_packet([(0, a[off[0]:off[1]])], 5000, 5000, pkt_type=fpga.PKT_MINIMIZERS))
+        # two reads with different (gap_ref, gap_qry) in one packet stream
+        drv.submit(fpga.build_task_packet([(1, a[off[1]:off[2]])], 5000, 5000))
+        drv.submit(fpga.build_task_packet([(2, a[off[2]:off[3]])], 800, 600))
+        results = drv.wait_results(3)
+        st = drv.stats()
+    got = {}
+    for raw in results:
+        for read_id, err, seeds in fpga.parse_result_packet(raw):
+            got[read_id] = (err, seeds)
+    assert got[0][0] == 1 and got[0][1] is None and st["err_reads"] == 1
+    for rid, (gx, gy) in ((1, (5000, 5000)), (2, (800, 600))):
+        pr = P.preset("map-ont", max_dist_x=gx, max_dist_y=gy)
+        ar = np.ascontiguousarray(a[off[rid]:off[rid + 1]])
+        f, p, v, _ = ol.oracle_fpv(pr, ar)
+        assert got[rid][1].tobytes() == ol.oracle_compact(pr, ar, f, p, v).tobytes()

@@ -17,12 +17,15 @@ def dev():
         yield d
 
 
-@pytest.mark.parametrize("ring", [128, 256, 512])
+@pytest.mark.parametrize("ring,general", [(128, False), (256, False), (512, False), (128, True), (256, True)])
 @pytest.mark.parametrize("name", golden_names())
-def test_golden_fixture_bit_exact(dev, name, ring):
+def test_golden_fixture_bit_exact(dev, name, ring, general):
+    """Every fixture through both variants of the DP kernel (table-driven fast path / general 64-bit path)
+    and every LDS ring size (small rings push the long scans onto the deep, global-memory path)."""
     g = load_golden(name)
     par = params_from(g["params"])
-    dev._check(dev._lib.chaindp_set_ring(dev._ctx, ring))
+    dev.set_ring(ring)
+    dev.set_variant(general)
     f, p, v = dev.chain_batch(par, g["off"], g["anchors"])
     assert np.array_equal(f, g["f"]), (name, "f", int(np.flatnonzero(f != g["f"])[0]))
     assert np.array_equal(p, g["p"]), (name, "p", int(np.flatnonzero(p != g["p"])[0]))
@@ -49,7 +52,8 @@ CASES = [  # generator, generator overrides, DP preset, DP overrides, reads, per
 
 @pytest.mark.parametrize("gen,gen_over,preset,par_over,n_reads,per_read", CASES)
 def test_seeded_batches_match_oracle(dev, gen, gen_over, preset, par_over, n_reads, per_read):
-    dev._check(dev._lib.chaindp_set_ring(dev._ctx, 256))
+    dev.set_ring(128)
+    dev.set_variant(False)
     par = P.preset(preset, **par_over)
     off, a = ag.generate(gen, n_reads=n_reads, seed=1234, **gen_over)
     n_segs = None
@@ -72,7 +76,33 @@ def test_seeded_batches_match_oracle(dev, gen, gen_over, preset, par_over, n_rea
         assert seeds[int(soff[r]):int(soff[r + 1])].tobytes() == exp.tobytes(), (gen, preset, r)
 
 
+def test_general_variant_on_seeded_batches(dev):
+    dev.set_ring(256)
+    dev.set_variant(True)
+    try:
+        for gen, preset, n_reads in (("ava-ont", "ava-ont", 100), ("dense", "ava-ont", 3), ("ties", "map-ont", 60)):
+            par = P.preset(preset)
+            off, a = ag.generate(gen, n_reads=n_reads, seed=4321)
+            f, p, v = dev.chain_batch(par, off, a)
+            of, op, ov, _ = ol.oracle_batch(par, off, a, threads=8)
+            assert np.array_equal(f, of) and np.array_equal(p, op) and np.array_equal(v, ov), (gen, preset)
+    finally:
+        dev.set_variant(False)
+
+
+def test_large_bw_takes_the_general_path(dev):
+    """bw above the cost table's limit (and a huge max_dist_x, where 32-bit ring arithmetic is not provably
+    exact) must fall back to the general variant and still match."""
+    dev.set_ring(128)
+    par = P.preset("map-ont", bw=6000, max_dist_x=40_000_000, max_dist_y=20000)
+    off, a = ag.generate("ties", n_reads=30, seed=9)
+    f, p, v = dev.chain_batch(par, off, a)
+    of, op, ov, _ = ol.oracle_batch(par, off, a, threads=8)
+    assert np.array_equal(f, of) and np.array_equal(p, op) and np.array_equal(v, ov)
+
+
 def test_edge_batches(dev):
+    dev.set_ring(128)
     par = P.preset("map-ont")
     # empty batch, batch of empty reads, a single one-anchor read
     f, p, v = dev.chain_batch(par, np.zeros(1, np.int64), np.zeros((0, 2), np.uint64))
@@ -117,6 +147,7 @@ def test_rejects_bad_arguments(dev):
 def test_run_is_idempotent_and_staged_api(dev):
     par = P.preset("ava-ont")
     off, a = ag.generate("ava-ont", n_reads=50, seed=77)
+    dev.set_ring(128)
     dev.upload(off, a)
     dev.run(par); dev.sync()
     f1, p1, v1 = dev.download()
