@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--ring", type=int, default=0, help="LDS ring capacity override (128/256/512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-anchors", type=int, default=40_000_000)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (16 = one GPU's share of the box)")
+    ap.add_argument("--host-threads", type=int, default=16, help="host threads of the synthetic generator")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -58,7 +60,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from minimap2_chaindp_amd import anchorgen, chaindp, params
+    from minimap2_chaindp_amd import chaindp, params, shard
 
     if not torch.cuda.is_available() or chaindp.device_count() <= 0:
         raise SystemExit("bench.py needs a GPU: the chaining DP has no CPU fallback")
@@ -73,7 +75,7 @@ def main():
     # ---- this rank's shard of the job, generated on the host, then made resident in HBM
     n_reads = args.reads_per_gpu
     t_gen = time.time()
-    off, anchors = anchorgen.generate(gen_preset, n_reads=n_reads, seed=SEED, first_read=rank * n_reads)
+    off, anchors = shard.generate_shard(gen_preset, rank, world, n_reads, SEED, threads=args.host_threads)
     t_gen = time.time() - t_gen
     total = int(off[-1])
     dev = chaindp.Device(local_rank, max_anchors=total + 1, max_reads=n_reads + 1, ring=args.ring or None)
@@ -104,16 +106,9 @@ def main():
     stats = dev.stats()
 
     # max over ranks of the timed region; sum of anchors
+    elapsed_max, total_all = shard.reduce_job(elapsed, total, dist if world > 1 else None, device="cuda")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_max = float(t.item())
-        n = torch.tensor([total], dtype=torch.int64, device="cuda")
-        dist.all_reduce(n, op=dist.ReduceOp.SUM)
-        total_all = int(n.item())
         dist.barrier()
-    else:
-        elapsed_max, total_all = elapsed, total
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -154,7 +149,7 @@ def main():
             "host": {"generate_s": t_gen, "upload_s": t_up, "upload_GBps": total * 16 / t_up / 1e9 if t_up > 0 else None},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(par, off, anchors, args.cpu_sample_anchors)
+            out["cpu_baseline"] = cpu_baseline(par, off, anchors, args.cpu_sample_anchors, args.cpu_threads)
         print(json.dumps(out), flush=True)
 
     dev.close()
@@ -162,31 +157,30 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(par, off, anchors, sample_anchors):
-    """The reference's per-read call (malloc, recurrence, compaction, free) on all host cores, over the
-    first reads of the same batch that hold about `sample_anchors` anchors."""
+def cpu_baseline(par, off, anchors, sample_anchors, threads):
+    """The reference's per-read call (malloc, recurrence, compaction, free) over the first reads of the
+    same batch that hold about `sample_anchors` anchors, on `threads` host threads (default 16: the CPU
+    share of one GPU on the box), repeated until it amounts to roughly 10-30 s of CPU work."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     n = int(np.searchsorted(off, sample_anchors, side="left"))
     n = max(1, min(n, len(off) - 1))
     soff = np.ascontiguousarray(off[:n + 1])
     sa = np.ascontiguousarray(anchors[:int(soff[-1])])
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
     use_ref = ol.have_ref()
-    sec, _ = ol.time_top(par, soff, sa, threads=cores, use_ref=use_ref)
-    sec1, _ = ol.time_top(par, soff[:max(2, n // cores + 1)], sa, threads=1, use_ref=use_ref)
-    n1 = int(soff[max(1, n // cores)])
+    n1 = max(1, n // 64)                                        # single-core probe on 1/64 of the sample
+    sec1, _ = ol.time_top(par, np.ascontiguousarray(soff[:n1 + 1]), sa, threads=1, use_ref=use_ref)
+    rate1 = int(soff[n1]) / sec1
+    reps = int(max(1, min(8, round(15.0 * rate1 / int(soff[-1])))))   # ~15 core-seconds in total
+    sec, _ = ol.time_top(par, soff, sa, threads=threads, use_ref=use_ref, reps=reps)
     return {
-        "value": int(soff[-1]) / sec, "unit": "anchors/s", "cores": cores,
+        "value": int(soff[-1]) * reps / sec, "unit": "anchors/s", "cores": threads,
         "kind": "reference" if use_ref else "port",
-        "sample": f"first {n} reads ({int(soff[-1])} anchors) of the same batch, per-read mm_chain_dp_fpga-shaped call "
-                  f"(malloc + recurrence + compaction + free), reads dealt to {cores} threads by anchor count",
-        "seconds": sec,
-        "single_core_value": n1 / sec1 if sec1 > 0 else None,
+        "sample": f"first {n} reads ({int(soff[-1])} anchors) of the same batch x {reps} passes, per-read "
+                  f"mm_chain_dp_fpga call (malloc + recurrence + compaction + free), reads dealt to {threads} threads "
+                  f"by anchor count, clock from all-workers-ready to last-worker-done",
+        "seconds": sec, "cpu_core_seconds": sec * threads,
+        "single_core_value": rate1, "host_logical_cpus": os.cpu_count(),
     }
 
 

@@ -7,4 +7,4 @@ this package is its host-side mirror for tests and benchmarks:
   params     DP parameter presets as the reference derives them
   anchorgen  seeded ONT-shaped synthetic anchor batches
 """
-__all__ = ["chaindp", "fpga", "params", "anchorgen"]
+__all__ = ["chaindp", "fpga", "params", "anchorgen", "shard"]

@@ -1,0 +1,46 @@
+"""Read sharding across the GPUs of one node and the (only) collective steps of a multi-GPU run.
+
+Reads are independent DP problems, so a job is partitioned, not exchanged: rank r of W owns reads
+[r*reads_per_gpu, (r+1)*reads_per_gpu) of the seeded job (weak scaling: per-GPU work is fixed).  The
+only communication is the benchmark's barrier and two scalar reductions (max time, sum of anchors),
+done with torch.distributed on whatever backend the process group uses (nccl = RCCL on the GPU box,
+gloo in the CPU tests).
+"""
+import numpy as np
+
+from . import anchorgen
+
+
+def shard_range(rank, world, reads_per_gpu):
+    if not (0 <= rank < world):
+        raise ValueError("rank outside world")
+    return rank * reads_per_gpu, reads_per_gpu
+
+
+def generate_shard(preset, rank, world, reads_per_gpu, seed, threads=None, **overrides):
+    first, n = shard_range(rank, world, reads_per_gpu)
+    return anchorgen.generate(preset, n_reads=n, seed=seed, first_read=first, threads=threads, **overrides)
+
+
+def split_by_anchors(off, parts):
+    """Cut points (read indices, len parts+1) that deal a batch's reads into `parts` contiguous pieces of
+    near-equal anchor count (partition by cumulative anchors, not by read count)."""
+    off = np.asarray(off, np.int64)
+    total = int(off[-1])
+    cuts = [0]
+    for k in range(1, parts):
+        cuts.append(int(np.searchsorted(off, total * k // parts, side="left")))
+    cuts.append(len(off) - 1)
+    return np.maximum.accumulate(np.array(cuts, np.int64))
+
+
+def reduce_job(elapsed, anchors, dist=None, device=None):
+    """(max over ranks of elapsed, sum over ranks of anchors).  dist = torch.distributed or None."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(elapsed), int(anchors)
+    import torch
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    n = torch.tensor([anchors], dtype=torch.int64, device=device)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(n.item())

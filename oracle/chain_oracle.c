@@ -273,7 +273,8 @@ typedef struct {
 	int32_t *f, *p, *v;
 	int64_t r0, r1, evals;
 	co_ref_top_fn fn;
-	void **copies;
+	int reps;
+	pthread_barrier_t *start, *stop;
 	uint64_t checksum;
 } co_job_t;
 
@@ -334,55 +335,72 @@ static void *top_worker(void *arg)
 	co_job_t *jb = (co_job_t*)arg;
 	int64_t r;
 	uint64_t h = 0;
-	for (r = jb->r0; r < jb->r1; ++r) {
-		int64_t o = jb->off[r], n = jb->off[r + 1] - o;
-		co_params_t par = *jb->par;
-		uint32_t new_i = 0, k;
-		co_seed_t *s;
-		if (jb->n_segs) par.n_segs = jb->n_segs[r];
-		if (jb->fn) s = (co_seed_t*)jb->fn(par.max_dist_x, par.max_dist_y, par.bw, par.max_skip, par.min_sc,
-		                                   par.is_cdna, par.n_segs, n, jb->copies[r], &new_i);
-		else s = co_chain_top(&par, n, jb->a + o, &new_i);
-		for (k = 0; k < new_i; ++k) h = h * 1099511628211ULL + (uint64_t)(uint32_t)s[k].f * 31u + (uint32_t)s[k].p;
-		free(s);
+	int rep;
+	void ***copies = 0;
+	if (jb->fn) { /* the reference frees its input (chain.c:322): private malloc'd copies, made before the clock starts */
+		copies = (void***)malloc((size_t)jb->reps * sizeof(void**));
+		for (rep = 0; rep < jb->reps; ++rep) {
+			copies[rep] = (void**)malloc((size_t)(jb->r1 - jb->r0 + 1) * sizeof(void*));
+			for (r = jb->r0; r < jb->r1; ++r) {
+				size_t bytes = (size_t)(jb->off[r + 1] - jb->off[r]) * sizeof(co_anchor_t);
+				copies[rep][r - jb->r0] = malloc(bytes ? bytes : 1);
+				memcpy(copies[rep][r - jb->r0], jb->a + jb->off[r], bytes);
+			}
+		}
 	}
+	pthread_barrier_wait(jb->start);
+	for (rep = 0; rep < jb->reps; ++rep) {
+		for (r = jb->r0; r < jb->r1; ++r) {
+			int64_t o = jb->off[r], n = jb->off[r + 1] - o;
+			co_params_t par = *jb->par;
+			uint32_t new_i = 0, k;
+			co_seed_t *s;
+			if (jb->n_segs) par.n_segs = jb->n_segs[r];
+			if (jb->fn) s = (co_seed_t*)jb->fn(par.max_dist_x, par.max_dist_y, par.bw, par.max_skip, par.min_sc,
+			                                   par.is_cdna, par.n_segs, n, copies[rep][r - jb->r0], &new_i);
+			else s = co_chain_top(&par, n, jb->a + o, &new_i);
+			if (rep == 0) for (k = 0; k < new_i; ++k) h = h * 1099511628211ULL + (uint64_t)(uint32_t)s[k].f * 31u + (uint32_t)s[k].p;
+			free(s);
+		}
+	}
+	pthread_barrier_wait(jb->stop);
+	if (copies) { for (rep = 0; rep < jb->reps; ++rep) free(copies[rep]); free(copies); }
 	jb->checksum = h;
 	return 0;
 }
 
 double co_time_top(const co_params_t *par, int64_t n_reads, const int64_t *off,
                    const co_anchor_t *a, const int32_t *n_segs_per_read,
-                   int threads, co_ref_top_fn fn, uint64_t *checksum)
+                   int threads, int reps, co_ref_top_fn fn, uint64_t *checksum)
 {
 	pthread_t *th;
 	co_job_t *jobs;
-	int64_t *cut, r;
-	void **copies = 0;
+	int64_t *cut;
+	pthread_barrier_t start, stop;
 	struct timespec t0, t1;
 	uint64_t h = 0;
 	int k;
 	if (threads < 1) threads = 1;
+	if (reps < 1) reps = 1;
 	th = (pthread_t*)malloc(threads * sizeof(pthread_t));
 	jobs = (co_job_t*)calloc(threads, sizeof(co_job_t));
 	cut = (int64_t*)malloc((threads + 1) * 8);
 	split_by_anchors(n_reads, off, threads, cut);
-	if (fn) { /* the reference frees its input (chain.c:322): hand it private malloc'd copies */
-		copies = (void**)malloc((size_t)n_reads * sizeof(void*));
-		for (r = 0; r < n_reads; ++r) {
-			size_t bytes = (size_t)(off[r + 1] - off[r]) * sizeof(co_anchor_t);
-			copies[r] = malloc(bytes ? bytes : 1);
-			memcpy(copies[r], a + off[r], bytes);
-		}
-	}
-	clock_gettime(CLOCK_MONOTONIC, &t0);
+	pthread_barrier_init(&start, 0, (unsigned)threads + 1);
+	pthread_barrier_init(&stop, 0, (unsigned)threads + 1);
 	for (k = 0; k < threads; ++k) {
 		jobs[k].par = par, jobs[k].off = off, jobs[k].a = a, jobs[k].n_segs = n_segs_per_read;
-		jobs[k].r0 = cut[k], jobs[k].r1 = cut[k + 1], jobs[k].fn = fn, jobs[k].copies = copies;
+		jobs[k].r0 = cut[k], jobs[k].r1 = cut[k + 1], jobs[k].fn = fn, jobs[k].reps = reps;
+		jobs[k].start = &start, jobs[k].stop = &stop;
 		pthread_create(&th[k], 0, top_worker, &jobs[k]);
 	}
-	for (k = 0; k < threads; ++k) { pthread_join(th[k], 0); h ^= jobs[k].checksum + (uint64_t)k; }
+	pthread_barrier_wait(&start);          /* every worker is up and has its private input copies */
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	pthread_barrier_wait(&stop);           /* the slowest worker has finished its last read */
 	clock_gettime(CLOCK_MONOTONIC, &t1);
+	for (k = 0; k < threads; ++k) { pthread_join(th[k], 0); h ^= jobs[k].checksum + (uint64_t)k; }
+	pthread_barrier_destroy(&start); pthread_barrier_destroy(&stop);
 	if (checksum) *checksum = h;
-	free(copies); free(th); free(jobs); free(cut);
+	free(th); free(jobs); free(cut);
 	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

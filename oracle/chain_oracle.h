@@ -77,14 +77,16 @@ int64_t co_batch_fpv(const co_params_t *par, int64_t n_reads, const int64_t *off
                      int32_t *f, int32_t *p, int32_t *v, int threads);
 
 /* Timed variant: the full reference-shaped per-read call (malloc scratch,
- * recurrence, compaction, free) like mm_chain_dp_fpga, multi-threaded;
- * returns wall seconds.  fn == NULL uses co_chain_top; otherwise fn must have
- * the reference signature (oracle/_ref's mm_chain_dp_fpga), which frees its
- * input, so each read is copied to a malloc'd buffer before the clock starts. */
+ * recurrence, compaction, free) like mm_chain_dp_fpga, on `threads` pthreads,
+ * the batch processed `reps` times; returns wall seconds between "all workers
+ * ready" and "last worker done" (thread start-up and input copies excluded).
+ * fn == NULL uses co_chain_top; otherwise fn must have the reference signature
+ * (oracle/_ref's mm_chain_dp_fpga), which frees its input, so every worker
+ * makes private malloc'd copies of its reads before the clock starts. */
 typedef void *(*co_ref_top_fn)(int, int, int, int, int, int, int, int64_t, void *, uint32_t *);
 double co_time_top(const co_params_t *par, int64_t n_reads, const int64_t *off,
                    const co_anchor_t *a, const int32_t *n_segs_per_read,
-                   int threads, co_ref_top_fn fn, uint64_t *checksum);
+                   int threads, int reps, co_ref_top_fn fn, uint64_t *checksum);
 
 #ifdef __cplusplus
 }

@@ -46,7 +46,7 @@ def oracle():
         lib.co_batch_fpv.restype = C.c_int64
         lib.co_batch_fpv.argtypes = [P, C.c_int64] + [C.c_void_p] * 6 + [C.c_int]
         lib.co_time_top.restype = C.c_double
-        lib.co_time_top.argtypes = [P, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
+        lib.co_time_top.argtypes = [P, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
         lib.wm_batch_fpv.restype = C.c_int64
         lib.wm_batch_fpv.argtypes = [P, C.c_int64] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
         lib.co_radix_sort_128x.argtypes = [C.c_void_p, C.c_void_p]
@@ -166,7 +166,7 @@ def wave_model_batch(par, off, a, n_segs=None, ring=128):
     return f[:tot], p[:tot], v[:tot], dict(zip(names, stats.tolist()))
 
 
-def time_top(par, off, a, threads, use_ref=False, n_segs=None):
+def time_top(par, off, a, threads, use_ref=False, n_segs=None, reps=1):
     """Wall seconds of the per-read top call over the batch (cpu_baseline leg)."""
     fn = None
     if use_ref:
@@ -174,5 +174,5 @@ def time_top(par, off, a, threads, use_ref=False, n_segs=None):
     ns = None if n_segs is None else np.ascontiguousarray(n_segs, np.int32)
     chk = C.c_uint64(0)
     sec = oracle().co_time_top(C.byref(_co(par)), len(off) - 1, off.ctypes.data, a.ctypes.data,
-                               None if ns is None else ns.ctypes.data, threads, fn, C.byref(chk))
+                               None if ns is None else ns.ctypes.data, threads, reps, fn, C.byref(chk))
     return sec, chk.value
