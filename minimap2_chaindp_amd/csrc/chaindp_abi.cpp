@@ -36,7 +36,7 @@ struct chaindp_ctx {
 	Unit *d_units = nullptr;
 	unsigned long long *d_counters = nullptr;
 	chaindp::PrepassScratch pre = {nullptr, nullptr, nullptr};
-	int16_t *d_lut = nullptr;
+	uint16_t *d_lut = nullptr;
 	size_t lut_bytes = 0;
 	bool use_lut = true;
 	// compaction (allocated on first use)
@@ -186,11 +186,11 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, d_f, d_p, d_v, ctx->d_tg));
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[1], st));
 	// per-read gap-cost table for the fast variant (skipped when the table would not apply)
-	int16_t *lut = nullptr;
+	uint16_t *lut = nullptr;
 	int lut_stride = 0;
 	if (ctx->use_lut && !q.is_cdna && q.bw <= CHAINDP_LUT_MAX_BW && n_reads > 0) {
 		lut_stride = (q.bw + 1 + 7) & ~7;
-		const size_t need = (size_t)n_reads * lut_stride * sizeof(int16_t);
+		const size_t need = (size_t)n_reads * lut_stride * sizeof(uint16_t);
 		if (need > ctx->lut_bytes) {
 			HIP_TRY(ctx, hipStreamSynchronize(st));
 			if (ctx->d_lut) HIP_TRY(ctx, hipFree(ctx->d_lut));

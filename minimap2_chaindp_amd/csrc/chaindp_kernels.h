@@ -31,15 +31,15 @@ hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, in
                           unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
                           int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg);
 
-// Per-read gap-cost table (int16, negated), lut_stride entries per read (multiple of 8); usable while
+// Per-read gap-cost table (uint16), lut_stride entries per read (multiple of 8); usable while
 // bw <= CHAINDP_LUT_MAX_BW.  d_lut == nullptr makes every unit take the general (f64) variant.
 #define CHAINDP_LUT_MAX_BW 4095
 hipError_t launch_lut(hipStream_t st, const Params &par, int64_t n_reads, const int64_t *d_off,
-                      const unsigned long long *d_sumq, int lut_stride, int16_t *d_lut);
+                      const unsigned long long *d_sumq, int lut_stride, uint16_t *d_lut);
 size_t chain_lds_bytes(int ring, int lut_stride);
 
 hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
-                        const int32_t *d_n_segs, const unsigned long long *d_sumq, const int16_t *d_lut, int lut_stride,
+                        const int32_t *d_n_segs, const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
                         const Unit *d_units, const unsigned long long *d_counters,
                         int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg);
 

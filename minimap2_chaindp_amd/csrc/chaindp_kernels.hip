@@ -257,11 +257,11 @@ __global__ __launch_bounds__(256) void k_emit_units(int64_t n_reads, int64_t n_w
 // For a pair of anchors of the same segment in a non-cDNA run the gap cost depends only on
 // dd = |dr - dq| <= bw and on the read's avg_qspan (chain.c:264,272):
 //     cost(dd) = (int)(dd * .01 * avg_qspan) + (ilog2(dd) >> 1)
-// so it is tabulated once per read (bw+1 entries, stored negated as int16) with exactly the
+// so it is tabulated once per read (bw+1 entries, uint16) with exactly the
 // reference's f32/f64 operations, and the hot loop does an LDS lookup instead of f64 arithmetic.
 __global__ __launch_bounds__(256) void k_build_lut(Params par, int64_t n_reads, const int64_t *__restrict__ off,
                                                    const unsigned long long *__restrict__ sumq, int lut_stride,
-                                                   int16_t *__restrict__ lut)
+                                                   uint16_t *__restrict__ lut)
 {
 	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
 		const int64_t n = off[r + 1] - off[r];
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_build_lut(Params par, int64_t n_reads, 
 		for (int dd = threadIdx.x; dd <= par.bw; dd += blockDim.x) {
 			const int lg = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
 			const int lin = (int)((double)dd * .01 * avgd);
-			lut[r * lut_stride + dd] = (int16_t)(-(lin + (lg >> 1)));
+			lut[r * lut_stride + dd] = (uint16_t)(lin + (lg >> 1));
 		}
 	}
 }
@@ -300,13 +300,14 @@ __device__ __forceinline__ uint32_t absdiff_u32(uint32_t x, uint32_t y)
 
 // Per-unit constants and the LDS carve-up.  Ring entry k (16 B): x.lo, qpos, f, p (unit-relative);
 // side arrays: mark tag t[], v[], and (general variant only) x.hi[], y.hi[]; then the read's cost table.
+// During step i the ring holds anchors i-RING .. i-1 (entry i is written at the end of step i).
 struct UnitCtx {
 	const ulonglong2 *a;
 	int32_t *f, *p, *v, *tg;
 	uint32_t *s_w;          // ring entries, 4 dwords each
 	int *s_t, *s_v;
 	uint32_t *s_xhi, *s_yhi;
-	const int16_t *s_lut;
+	const uint16_t *s_lut;
 	int64_t base;
 	uint64_t maxx;
 	double avgd;
@@ -315,144 +316,179 @@ struct UnitCtx {
 	bool seg_rule;
 };
 
-// One chunk of 64 predecessors of anchor i (unit-relative), j = i-1-kb0-lane.
-//   GEN  = false: fast variant -- every anchor of the read has segment id 0, not cDNA, cost table in LDS,
-//                 and max_dist_x * RING < 2^32, so that all in-ring differences are exact in 32 bits.
-//   GEN  = true : the reference's general formulas in 64-bit arithmetic.
-//   DEEP = true : the predecessors are older than the ring and come from global memory (always general math).
-// Returns true when the scan for anchor i is complete (break taken, or window / unit exhausted).
-template <int RING, bool GEN, bool DEEP>
-__device__ __forceinline__ bool scan_chunk(const UnitCtx &c, const ulonglong2 &an, int ii, int i, int kb0, int qi, int span,
-                                           int &max_f, int &max_j, int &n_skip)
+// What one chunk of 64 predecessors (lane k <-> j = i-1-kb0-k) contributes before the serial semantics are applied.
+struct Pairs {
+	uint64_t ok;     // lanes that pass the filters of chain.c:252-261
+	int sc;          // their score incl. f[j] (chain.c:262-273); INT_MIN on the other lanes
+	int pj;          // p[j] (unit-relative) where ok
+	bool cont;       // the chunk's last lane is still inside the window and the unit: another chunk may follow
+};
+
+// Fast variant (see k_chain_units): every difference is exact in 32 bits, same segment everywhere, cost from
+// the LDS table.  Slots that no anchor of this unit has been written to yet hold x = x_first - max_dist_x - 2
+// (set at unit start), so lanes with j < 0 fail the window test like any out-of-window lane.
+template <int RING>
+__device__ __forceinline__ Pairs eval_fast(const UnitCtx &c, uint32_t xi, int qi, int span, int i, int kb0)
 {
-	constexpr int MASK = RING - 1, DEPTH = RING - 64;
+	constexpr int MASK = RING - 1;
+	const int slot = (i - 1 - kb0 - c.lane) & MASK;
+	const uint4 e = *(const uint4*)(c.s_w + 4 * slot);
+	const uint32_t dr = xi - e.x;
+	const uint32_t dq = (uint32_t)qi - e.y;
+	const uint32_t maxx = (uint32_t)c.maxx;
+	const uint64_t m_win = __builtin_amdgcn_ballot_w64(dr - 1u < maxx);                  // chain.c:252 and dr != 0 (:257)
+	const uint64_t m_dq = __builtin_amdgcn_ballot_w64(dq - 1u < (uint32_t)c.mdq);        // dq > 0 (:257), dq <= both gaps (:258)
+	const uint32_t dd = absdiff_u32(dr, dq);
+	const uint64_t m_bw = __builtin_amdgcn_ballot_w64(dd <= (uint32_t)c.bw);             // chain.c:260
+	Pairs P;
+	P.ok = m_win & m_dq & m_bw;
+	int sc0 = (int)dq < (int)dr ? (int)dq : (int)dr;
+	sc0 = sc0 > span ? span : sc0;                                                       // chain.c:262-263
+	const uint32_t di = dd < (uint32_t)c.bw ? dd : (uint32_t)c.bw;
+	const int sc = sc0 + (int)e.z - (int)c.s_lut[di];                                    // chain.c:272-273 via the table
+	P.sc = __builtin_amdgcn_inverse_ballot_w64(P.ok) ? sc : INT_MIN;
+	P.pj = (int)e.w;
+	P.cont = (uint32_t)__builtin_amdgcn_readlane((int)dr, 63) <= maxx;
+	return P;
+}
+
+// General variant: the reference's formulas in 64-bit arithmetic.  DEEP = the predecessors are older than the
+// ring and come from global memory.
+template <int RING, bool DEEP>
+__device__ __forceinline__ Pairs eval_general(const UnitCtx &c, const ulonglong2 &an, int ii, int qi, int span, int i, int kb0)
+{
+	constexpr int MASK = RING - 1;
 	const int lane = c.lane;
-	const int tag = i + 1;
+	const uint64_t ri = readlane_u64(an.x, ii);
+	const int sidi = seg_of_hi((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(an.y >> 32), ii));
 	const bool inr = kb0 + lane < i;
 	const int j = i - 1 - kb0 - lane;
 	const int slot = j & MASK;
-	int fj = 0, pj = -1, sc;
-	bool live, ok;
-	if constexpr (!GEN && !DEEP) {
-		const uint32_t xi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)an.x, ii);
-		const uint4 e = *(const uint4*)(c.s_w + 4 * slot);
-		const uint32_t dr = xi - e.x;                               // exact: |x_i - x_j| < max_dist_x * RING < 2^32
-		const int dq = (int)((uint32_t)qi - e.y);
-		fj = (int)e.z; pj = (int)e.w;
-		live = inr && dr <= (uint32_t)c.maxx;                       // chain.c:252 (window) per lane
-		const uint32_t dd = absdiff_u32(dr, (uint32_t)dq);
-		ok = live && dr != 0 && (uint32_t)(dq - 1) < (uint32_t)c.mdq && dd <= (uint32_t)c.bw;   // chain.c:257-260, same segment
-		int sc0 = dq < (int)dr ? dq : (int)dr;
-		sc0 = sc0 > span ? span : sc0;                              // chain.c:262-263
-		const uint32_t di = dd < (uint32_t)c.bw ? dd : (uint32_t)c.bw;
-		sc = sc0 + fj + (int)c.s_lut[di];                           // chain.c:272-273 via the table
-	} else {
-		const uint64_t ri = readlane_u64(an.x, ii);
-		const uint32_t yhi_i = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(an.y >> 32), ii);
-		const int sidi = seg_of_hi(yhi_i);
-		uint64_t xj = 0;
-		int qj = 0;
-		uint32_t yhj = 0;
-		if constexpr (!DEEP) {
-			const uint4 e = *(const uint4*)(c.s_w + 4 * slot);
-			xj = (uint64_t)c.s_xhi[slot] << 32 | e.x; qj = (int)e.y; fj = (int)e.z; pj = (int)e.w; yhj = c.s_yhi[slot];
-		} else {
-			wave_global_fence();
-			if (inr) {
-				const ulonglong2 aj = c.a[c.base + j];
-				xj = aj.x; qj = (int)(uint32_t)aj.y; yhj = (uint32_t)(aj.y >> 32);
-				fj = c.f[c.base + j];
-				pj = c.p[c.base + j];
-				pj = pj < 0 ? -1 : pj - c.rel0;                     // stored read-relative
-			}
-		}
-		const uint64_t d64 = ri - xj;
-		live = inr && d64 <= c.maxx;                                // chain.c:252
-		const int dr = (int)d64;
-		const int dq = (int)((uint32_t)qi - (uint32_t)qj);
-		const bool same = seg_of_hi(yhj) == sidi;
-		const int dd = dr > dq ? dr - dq : dq - dr;
-		ok = live;
-		ok = ok && !((same && dr == 0) || dq <= 0);                 // chain.c:257
-		ok = ok && !((same && dq > c.mdy) || dq > c.mdx);           // chain.c:258
-		ok = ok && !(same && dd > c.bw);                            // chain.c:260
-		ok = ok && !(c.seg_rule && same && dr > c.mdy);             // chain.c:261
-		int sc0 = dq < dr ? dq : dr;
-		sc0 = sc0 > span ? span : sc0;
-		sc = pair_score(sc0, dd, dr, dq, same, c.is_cdna, c.avgd) + fj;   // chain.c:264-273
-	}
-	sc = ok ? sc : INT_MIN;
-
-	// marks of every filter-passing lane first (chain.c:281), then each lane reads its own.  A target still
-	// in the ring is marked in LDS, an older one in the global mark array.
-	const int lo_near = i - DEPTH;
-	if (ok && pj >= (lo_near > 0 ? lo_near : 0)) c.s_t[pj & MASK] = tag;
-	if (lo_near > 0) {
-		if (ok && pj >= 0 && pj < lo_near) c.tg[c.base + pj] = tag;
-	}
-	int tj = 0;
+	uint64_t xj = 0;
+	int qj = 0, fj = 0, pj = -1;
+	uint32_t yhj = 0;
 	if constexpr (!DEEP) {
-		wave_mem_fence();
-		tj = c.s_t[slot];
+		const uint4 e = *(const uint4*)(c.s_w + 4 * slot);
+		xj = (uint64_t)c.s_xhi[slot] << 32 | e.x; qj = (int)e.y; fj = (int)e.z; pj = (int)e.w; yhj = c.s_yhi[slot];
 	} else {
 		wave_global_fence();
-		if (inr) tj = c.tg[c.base + j];
+		if (inr) {
+			const ulonglong2 aj = c.a[c.base + j];
+			xj = aj.x; qj = (int)(uint32_t)aj.y; yhj = (uint32_t)(aj.y >> 32);
+			fj = c.f[c.base + j];
+			pj = c.p[c.base + j];
+			pj = pj < 0 ? -1 : pj - c.rel0;                     // stored read-relative
+		}
 	}
+	const uint64_t d64 = ri - xj;
+	const bool live = inr && d64 <= c.maxx;                     // chain.c:252 (window) per lane
+	const int dr = (int)d64;
+	const int dq = (int)((uint32_t)qi - (uint32_t)qj);
+	const bool same = seg_of_hi(yhj) == sidi;
+	const int dd = dr > dq ? dr - dq : dq - dr;
+	bool ok = live;
+	ok = ok && !((same && dr == 0) || dq <= 0);                 // chain.c:257
+	ok = ok && !((same && dq > c.mdy) || dq > c.mdx);           // chain.c:258
+	ok = ok && !(same && dd > c.bw);                            // chain.c:260
+	ok = ok && !(c.seg_rule && same && dr > c.mdy);             // chain.c:261
+	int sc0 = dq < dr ? dq : dr;
+	sc0 = sc0 > span ? span : sc0;
+	const int sc = pair_score(sc0, dd, dr, dq, same, c.is_cdna, c.avgd) + fj;   // chain.c:264-273
+	Pairs P;
+	P.ok = __builtin_amdgcn_ballot_w64(ok);
+	P.sc = ok ? sc : INT_MIN;
+	P.pj = pj;
+	P.cont = __builtin_amdgcn_ballot_w64(live) == ~0ull;
+	return P;
+}
 
+// Applies the serial semantics of chain.c:274-281 to one evaluated chunk.  Marks whose target is still in the
+// ring go to LDS.  Marks on older targets matter only if the scan later reaches a deep chunk; ring chunks do
+// not write them (replay_far_marks does, on demand); deep chunks write all of theirs to the global array.
+// Returns true when the scan for anchor i is complete (break taken, or window / unit exhausted).
+template <int RING, bool DEEP>
+__device__ __forceinline__ bool apply_chunk(const UnitCtx &c, const Pairs &P, int i, int kb0, int &max_f, int &max_j, int &n_skip)
+{
+	constexpr int MASK = RING - 1;
+	const int lane = c.lane;
+	const int tag = i + 1;
+	const int j = i - 1 - kb0 - lane;
+	int tj = 0;
+	if constexpr (!DEEP) {
+		const int lo = i - RING > 0 ? i - RING : 0;
+		const uint64_t near = P.ok & __builtin_amdgcn_ballot_w64(P.pj >= lo);
+		if (__builtin_amdgcn_inverse_ballot_w64(near)) c.s_t[P.pj & MASK] = tag;          // chain.c:281
+		wave_mem_fence();
+		tj = c.s_t[j & MASK];
+	} else {
+		if (__builtin_amdgcn_inverse_ballot_w64(P.ok) && P.pj >= 0) c.tg[c.base + P.pj] = tag;
+		wave_global_fence();
+		if (kb0 + lane < i) tj = c.tg[c.base + j];
+	}
 	// new running max? strictly greater than everything before it (chain.c:274)
-	const int incl = wave_scan_max(sc);
+	const int incl = wave_scan_max(P.sc);
 	int excl = wave_shift_up1(incl, max_f);
 	excl = excl > max_f ? excl : max_f;
-	const bool isA = ok && sc > excl;
-	const bool isB = ok && !isA && tj == tag;                       // chain.c:277
-	const uint64_t A = __builtin_amdgcn_ballot_w64(isA);
-	const uint64_t B = __builtin_amdgcn_ballot_w64(isB);
-	const bool all_live = __builtin_amdgcn_ballot_w64(live) == ~0ull;
-
+	const uint64_t A = P.ok & __builtin_amdgcn_ballot_w64(P.sc > excl);
+	const uint64_t B = P.ok & ~A & __builtin_amdgcn_ballot_w64(tj == tag);                // chain.c:277
 	// n_skip walk (chain.c:276,278): A lanes x -> max(x-1,0), B lanes x -> x+1, break when > max_skip
-	int kbrk = -1;
-	if (B == 0) {
-		n_skip -= __builtin_popcountll(A);
-		n_skip = n_skip < 0 ? 0 : n_skip;
-	} else if ((A & ~((B & (0 - B)) - 1)) == 0) {                   // every A lane precedes every B lane
+	const int hiA = 63 - __builtin_clzll(A | 1ull);                // only used when A != 0
+	bool brk;
+	uint64_t Ap = A;
+	if (B == 0 || A == 0 || hiA < __builtin_ctzll(B)) {            // every A lane precedes every B lane
 		int x = n_skip - __builtin_popcountll(A);
 		x = x < 0 ? 0 : x;
-		int need = c.max_skip - x + 1;
-		need = need < 1 ? 1 : need;
 		const int cb = __builtin_popcountll(B);
-		if (cb >= need) {
-			const uint64_t m = __builtin_amdgcn_ballot_w64(isB && lanes_below(B) == need - 1);
-			kbrk = __builtin_ctzll(m);
-		} else n_skip = x + cb;
-	} else {                                                         // general: clamped walk via prefix min
+		int need = c.max_skip - x + 1;                             // the break is the need-th B lane; it lies above every
+		need = need < 1 ? 1 : need;                                // A lane, so all A lanes count and its position is irrelevant
+		brk = cb >= need;
+		n_skip = x + cb;
+	} else {                                                       // general: clamped walk via prefix min
+		const bool isA = __builtin_amdgcn_inverse_ballot_w64(A), isB = __builtin_amdgcn_inverse_ballot_w64(B);
 		const int S = n_skip + lanes_below(B) + (int)isB - lanes_below(A) - (int)isA;
 		const int M = wave_scan_min(S);
 		const int x = S - (M < 0 ? M : 0);
-		const uint64_t m = __builtin_amdgcn_ballot_w64(isB && x > c.max_skip);
-		if (m) kbrk = __builtin_ctzll(m);
+		const uint64_t m = B & __builtin_amdgcn_ballot_w64(x > c.max_skip);
+		brk = m != 0;
+		if (brk) Ap = A & ((1ull << __builtin_ctzll(m)) - 1);
 		else n_skip = __builtin_amdgcn_readlane(x, 63);
 	}
 	// the last A lane before the break holds the final running max and its j
-	const uint64_t Ap = kbrk >= 0 ? (A & ((1ull << kbrk) - 1)) : A;
 	if (Ap) {
 		const int ka = 63 - __builtin_clzll(Ap);
-		max_f = __builtin_amdgcn_readlane(sc, ka);
+		max_f = __builtin_amdgcn_readlane(P.sc, ka);
 		max_j = i - 1 - kb0 - ka;
 	}
-	return kbrk >= 0 || !all_live;
+	return brk || !P.cont;
+}
+
+// Before the first deep chunk of anchor i: write the marks of the ring chunks whose targets are older than the
+// ring (skipped by apply_chunk<.., false>) into the global mark array.
+template <int RING, bool GEN>
+__device__ __forceinline__ void replay_far_marks(const UnitCtx &c, const ulonglong2 &an, int ii, uint32_t xi, int qi, int span, int i)
+{
+	for (int kb0 = 0; kb0 + 64 <= RING && kb0 < i; kb0 += 64) {
+		Pairs P;
+		if constexpr (GEN) P = eval_general<RING, false>(c, an, ii, qi, span, i, kb0);
+		else P = eval_fast<RING>(c, xi, qi, span, i, kb0);
+		if (__builtin_amdgcn_inverse_ballot_w64(P.ok) && P.pj >= 0 && P.pj < i - RING) c.tg[c.base + P.pj] = i + 1;
+	}
 }
 
 template <int RING, bool GEN>
 __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 {
-	constexpr int MASK = RING - 1, DEPTH = RING - 64;
+	constexpr int MASK = RING - 1;
 	const int lane = c.lane;
 	uint64_t x_carry = 0;
+	ulonglong2 an_next = make_ulonglong2(0, 0);
+	if (lane < room) an_next = c.a[c.base + lane];
 	for (int tile0 = 0;; tile0 += 64) {
 		const int64_t gi = c.base + tile0 + lane;
 		const bool have = tile0 + lane < room;
-		ulonglong2 an = make_ulonglong2(0, 0);
-		if (have) an = c.a[gi];
+		const ulonglong2 an = an_next;
+		an_next = make_ulonglong2(0, 0);
+		if (tile0 + 64 + lane < room) an_next = c.a[gi + 64];   // next tile in flight while this one is scored
 		// the unit ends at the first gap > max_dist_x (or at the end of the read)
 		uint64_t xp;
 		{
@@ -465,49 +501,53 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 		const int cnt = stop_m ? __builtin_ctzll(stop_m) : 64;
 		if (cnt == 0) break;
 		x_carry = readlane_u64(an.x, 63);
-		const int my_slot = (tile0 + lane) & MASK;
-		wave_mem_fence();
-		if (lane < cnt) {
-			*(uint2*)(c.s_w + 4 * my_slot) = make_uint2((uint32_t)an.x, (uint32_t)an.y);
-			if constexpr (GEN) { c.s_xhi[my_slot] = (uint32_t)(an.x >> 32); c.s_yhi[my_slot] = (uint32_t)(an.y >> 32); }
-		}
-		wave_mem_fence();
 
 		// v[i] = max(v[max_j], f[i]) (chain.c:284) is off the recurrence's critical path: the read of v[max_j]
 		// is issued at the end of step i and consumed one step later.
 		int pend_slot = -1, pend_mf = 0, pend_vj = INT_MIN;
 		for (int ii = 0; ii < cnt; ++ii) {
 			const int i = tile0 + ii;                          // unit-relative index of the anchor being scored
+			const uint32_t xi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)an.x, ii);
 			const int qi = __builtin_amdgcn_readlane((int)(uint32_t)an.y, ii);
 			const int span = span_of_hi((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(an.y >> 32), ii));
 			int max_f = span, max_j = -1, n_skip = 0;
 			for (int kb0 = 0; kb0 < i; kb0 += 64) {
 				bool done;
-				if (kb0 + 64 <= DEPTH) done = scan_chunk<RING, GEN, false>(c, an, ii, i, kb0, qi, span, max_f, max_j, n_skip);
-				else done = scan_chunk<RING, true, true>(c, an, ii, i, kb0, qi, span, max_f, max_j, n_skip);
+				if (kb0 + 64 <= RING) {
+					Pairs P;
+					if constexpr (GEN) P = eval_general<RING, false>(c, an, ii, qi, span, i, kb0);
+					else P = eval_fast<RING>(c, xi, qi, span, i, kb0);
+					done = apply_chunk<RING, false>(c, P, i, kb0, max_f, max_j, n_skip);
+				} else {
+					if (kb0 == RING) replay_far_marks<RING, GEN>(c, an, ii, xi, qi, span, i);
+					const Pairs P = eval_general<RING, true>(c, an, ii, qi, span, i, kb0);
+					done = apply_chunk<RING, true>(c, P, i, kb0, max_f, max_j, n_skip);
+				}
 				if (done) break;
 			}
-			// epilogue (chain.c:283-284)
+			// epilogue (chain.c:283-284): anchor i enters the ring; v of the previous anchor is completed
+			const int vprev = pend_vj > pend_mf ? pend_vj : pend_mf;
 			wave_mem_fence();
-			if (pend_slot >= 0) {
-				const int vprev = pend_vj > pend_mf ? pend_vj : pend_mf;
-				if (lane == 0) c.s_v[pend_slot] = vprev;
+			if (lane == ii) {
+				*(uint4*)(c.s_w + 4 * (i & MASK)) = make_uint4((uint32_t)an.x, (uint32_t)an.y, (uint32_t)max_f, (uint32_t)max_j);
+				if constexpr (GEN) { c.s_xhi[i & MASK] = (uint32_t)(an.x >> 32); c.s_yhi[i & MASK] = (uint32_t)(an.y >> 32); }
+				if (pend_slot >= 0) c.s_v[pend_slot] = vprev;
 			}
-			if (lane == 0) *(int2*)(c.s_w + 4 * (i & MASK) + 2) = make_int2(max_f, max_j);
 			wave_mem_fence();
 			pend_slot = i & MASK; pend_mf = max_f; pend_vj = INT_MIN;
 			if (max_j >= 0) {
-				if (i - max_j <= DEPTH) pend_vj = c.s_v[max_j & MASK];
+				if (i - max_j <= RING) pend_vj = c.s_v[max_j & MASK];
 				else { wave_global_fence(); pend_vj = c.v[c.base + max_j]; }
 			}
 		}
-		wave_mem_fence();
 		{
 			const int vprev = pend_vj > pend_mf ? pend_vj : pend_mf;
+			wave_mem_fence();
 			if (lane == 0) c.s_v[pend_slot] = vprev;
+			wave_mem_fence();
 		}
-		wave_mem_fence();
 		if (lane < cnt) {
+			const int my_slot = (tile0 + lane) & MASK;
 			const int2 fp = *(const int2*)(c.s_w + 4 * my_slot + 2);
 			c.f[gi] = fp.x;
 			c.p[gi] = fp.y < 0 ? -1 : fp.y + c.rel0;
@@ -521,7 +561,7 @@ template <int RING>
 __global__ __launch_bounds__(64) void k_chain_units(Params par, const int64_t *__restrict__ off,
                                                     const ulonglong2 *__restrict__ a, const int32_t *__restrict__ n_segs_pr,
                                                     const unsigned long long *__restrict__ sumq,
-                                                    const int16_t *__restrict__ lut, int lut_stride,
+                                                    const uint16_t *__restrict__ lut, int lut_stride,
                                                     const Unit *__restrict__ units,
                                                     const unsigned long long *__restrict__ counters,
                                                     int32_t *f, int32_t *p, int32_t *v, int32_t *tg)
@@ -535,13 +575,15 @@ __global__ __launch_bounds__(64) void k_chain_units(Params par, const int64_t *_
 	c.s_v = c.s_t + RING;
 	c.s_xhi = (uint32_t*)(c.s_v + RING);
 	c.s_yhi = c.s_xhi + RING;
-	int16_t *s_lut = (int16_t*)(c.s_yhi + RING);
+	uint16_t *s_lut = (uint16_t*)(c.s_yhi + RING);
 	c.s_lut = s_lut;
 	c.lane = threadIdx.x;
 	c.maxx = (uint64_t)(int64_t)par.max_dist_x;
 	c.mdx = par.max_dist_x; c.mdy = par.max_dist_y; c.bw = par.bw; c.max_skip = par.max_skip; c.is_cdna = par.is_cdna;
 	c.mdq = par.max_dist_x < par.max_dist_y ? par.max_dist_x : par.max_dist_y;   // dq > max_dist_y || dq > max_dist_x (same segment)
-	const bool x32_ok = (uint64_t)(int64_t)par.max_dist_x * (uint64_t)RING < (1ull << 32);
+	// 32-bit differences are exact while (RING + 1) * max_dist_x + 2 < 2^32: consecutive anchors of a unit are at
+	// most max_dist_x apart, the ring spans RING of them, and unwritten slots sit max_dist_x + 2 below the unit start
+	const bool x32_ok = ((uint64_t)(int64_t)par.max_dist_x + 1) * (uint64_t)(RING + 1) < (1ull << 32);
 	const int lane = threadIdx.x;
 
 	for (int64_t ub = blockIdx.x; ub < (int64_t)counters[0]; ub += gridDim.x) {
@@ -560,6 +602,8 @@ __global__ __launch_bounds__(64) void k_chain_units(Params par, const int64_t *_
 		if (!general) {
 			const uint4 *src = (const uint4*)(lut + (int64_t)u.read * lut_stride);   // lut_stride is a multiple of 8 entries (16 B)
 			for (int k = lane; k * 8 < lut_stride; k += 64) ((uint4*)s_lut)[k] = src[k];
+			const uint32_t x_none = (uint32_t)a[u.start].x - (uint32_t)c.maxx - 2u;  // "no anchor here yet": fails the window test
+			for (int k = lane; k < RING; k += 64) *(uint4*)(c.s_w + 4 * k) = make_uint4(x_none, 0u, 0u, 0xffffffffu);
 		}
 		wave_mem_fence();
 		if (general) run_unit<RING, true>(c, re - u.start);
@@ -600,7 +644,7 @@ size_t chain_lds_bytes(int ring, int lut_stride)
 }
 
 hipError_t launch_lut(hipStream_t st, const Params &par, int64_t n_reads, const int64_t *d_off,
-                      const unsigned long long *d_sumq, int lut_stride, int16_t *d_lut)
+                      const unsigned long long *d_sumq, int lut_stride, uint16_t *d_lut)
 {
 	if (n_reads <= 0) return hipSuccess;
 	int64_t blocks = n_reads < 65536 ? n_reads : 65536;
@@ -609,7 +653,7 @@ hipError_t launch_lut(hipStream_t st, const Params &par, int64_t n_reads, const 
 }
 
 hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
-                        const int32_t *d_n_segs, const unsigned long long *d_sumq, const int16_t *d_lut, int lut_stride,
+                        const int32_t *d_n_segs, const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
                         const Unit *d_units, const unsigned long long *d_counters,
                         int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg)
 {
