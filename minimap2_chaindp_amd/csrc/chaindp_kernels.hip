@@ -308,6 +308,7 @@ struct UnitCtx {
 	int *s_t, *s_v;
 	uint32_t *s_xhi, *s_yhi;
 	const uint16_t *s_lut;
+	int *s_dummy;           // sink for lanes that have no mark to write
 	int64_t base;
 	uint64_t maxx;
 	double avgd;
@@ -402,6 +403,14 @@ __device__ __forceinline__ Pairs eval_general(const UnitCtx &c, const ulonglong2
 	return P;
 }
 
+// (1 << n) - 1 for n in [0, 63] as one scalar instruction
+__device__ __forceinline__ uint64_t low_mask64(int n)
+{
+	uint64_t m;
+	asm("s_bfm_b64 %0, %1, 0" : "=s"(m) : "s"(n));
+	return m;
+}
+
 // Applies the serial semantics of chain.c:274-281 to one evaluated chunk.  Marks whose target is still in the
 // ring go to LDS.  Marks on older targets matter only if the scan later reaches a deep chunk; ring chunks do
 // not write them (replay_far_marks does, on demand); deep chunks write all of theirs to the global array.
@@ -415,9 +424,11 @@ __device__ __forceinline__ bool apply_chunk(const UnitCtx &c, const Pairs &P, in
 	const int j = i - 1 - kb0 - lane;
 	int tj = 0;
 	if constexpr (!DEEP) {
+		// lanes without a mark to make store into a dummy word instead of being masked off (no exec juggling)
 		const int lo = i - RING > 0 ? i - RING : 0;
 		const uint64_t near = P.ok & __builtin_amdgcn_ballot_w64(P.pj >= lo);
-		if (__builtin_amdgcn_inverse_ballot_w64(near)) c.s_t[P.pj & MASK] = tag;          // chain.c:281
+		int *dst = __builtin_amdgcn_inverse_ballot_w64(near) ? &c.s_t[P.pj & MASK] : c.s_dummy;
+		*dst = tag;                                                                       // chain.c:281
 		wave_mem_fence();
 		tj = c.s_t[j & MASK];
 	} else {
@@ -432,34 +443,36 @@ __device__ __forceinline__ bool apply_chunk(const UnitCtx &c, const Pairs &P, in
 	const uint64_t A = P.ok & __builtin_amdgcn_ballot_w64(P.sc > excl);
 	const uint64_t B = P.ok & ~A & __builtin_amdgcn_ballot_w64(tj == tag);                // chain.c:277
 	// n_skip walk (chain.c:276,278): A lanes x -> max(x-1,0), B lanes x -> x+1, break when > max_skip
-	const int hiA = 63 - __builtin_clzll(A | 1ull);                // only used when A != 0
-	bool brk;
-	uint64_t Ap = A;
-	if (B == 0 || A == 0 || hiA < __builtin_ctzll(B)) {            // every A lane precedes every B lane
+	const int hiA = 63 - __builtin_clzll(A | 1ull);                // highest A lane (0 when A is empty or {0})
+	if ((B & low_mask64(hiA)) == 0) {                              // every A lane precedes every B lane (or one set is empty)
+		if (A) {                                                   // the break, if any, is a B lane above every A lane: all A
+			max_f = __builtin_amdgcn_readlane(P.sc, hiA);          // lanes count, and the last one holds the running max
+			max_j = i - 1 - kb0 - hiA;
+		}
 		int x = n_skip - __builtin_popcountll(A);
 		x = x < 0 ? 0 : x;
 		const int cb = __builtin_popcountll(B);
-		int need = c.max_skip - x + 1;                             // the break is the need-th B lane; it lies above every
-		need = need < 1 ? 1 : need;                                // A lane, so all A lanes count and its position is irrelevant
-		brk = cb >= need;
+		int need = c.max_skip - x + 1;
+		need = need < 1 ? 1 : need;
+		if (cb >= need) return true;                               // break taken (chain.c:278-279)
 		n_skip = x + cb;
-	} else {                                                       // general: clamped walk via prefix min
-		const bool isA = __builtin_amdgcn_inverse_ballot_w64(A), isB = __builtin_amdgcn_inverse_ballot_w64(B);
-		const int S = n_skip + lanes_below(B) + (int)isB - lanes_below(A) - (int)isA;
-		const int M = wave_scan_min(S);
-		const int x = S - (M < 0 ? M : 0);
-		const uint64_t m = B & __builtin_amdgcn_ballot_w64(x > c.max_skip);
-		brk = m != 0;
-		if (brk) Ap = A & ((1ull << __builtin_ctzll(m)) - 1);
-		else n_skip = __builtin_amdgcn_readlane(x, 63);
+		return !P.cont;
 	}
-	// the last A lane before the break holds the final running max and its j
+	// general: clamped walk via prefix min
+	const bool isA = __builtin_amdgcn_inverse_ballot_w64(A), isB = __builtin_amdgcn_inverse_ballot_w64(B);
+	const int S = n_skip + lanes_below(B) + (int)isB - lanes_below(A) - (int)isA;
+	const int M = wave_scan_min(S);
+	const int x = S - (M < 0 ? M : 0);
+	const uint64_t m = B & __builtin_amdgcn_ballot_w64(x > c.max_skip);
+	const uint64_t Ap = m ? (A & ((1ull << __builtin_ctzll(m)) - 1)) : A;   // A lanes before the break
 	if (Ap) {
 		const int ka = 63 - __builtin_clzll(Ap);
 		max_f = __builtin_amdgcn_readlane(P.sc, ka);
 		max_j = i - 1 - kb0 - ka;
 	}
-	return brk || !P.cont;
+	if (m) return true;
+	n_skip = __builtin_amdgcn_readlane(x, 63);
+	return !P.cont;
 }
 
 // Before the first deep chunk of anchor i: write the marks of the ring chunks whose targets are older than the
@@ -575,7 +588,8 @@ __global__ __launch_bounds__(64) void k_chain_units(Params par, const int64_t *_
 	c.s_v = c.s_t + RING;
 	c.s_xhi = (uint32_t*)(c.s_v + RING);
 	c.s_yhi = c.s_xhi + RING;
-	uint16_t *s_lut = (uint16_t*)(c.s_yhi + RING);
+	c.s_dummy = (int*)(c.s_yhi + RING);                         // 16 B: one dummy word + padding
+	uint16_t *s_lut = (uint16_t*)(c.s_yhi + RING + 4);
 	c.s_lut = s_lut;
 	c.lane = threadIdx.x;
 	c.maxx = (uint64_t)(int64_t)par.max_dist_x;
@@ -640,7 +654,7 @@ size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *bl
 
 size_t chain_lds_bytes(int ring, int lut_stride)
 {
-	return (size_t)ring * 32 + (size_t)lut_stride * 2;
+	return (size_t)ring * 32 + 16 + (size_t)lut_stride * 2;
 }
 
 hipError_t launch_lut(hipStream_t st, const Params &par, int64_t n_reads, const int64_t *d_off,
