@@ -571,7 +571,7 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 }
 
 template <int RING>
-__global__ __launch_bounds__(64) void k_chain_units(Params par, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_chain_units(Params par, const int64_t *__restrict__ off,
                                                     const ulonglong2 *__restrict__ a, const int32_t *__restrict__ n_segs_pr,
                                                     const unsigned long long *__restrict__ sumq,
                                                     const uint16_t *__restrict__ lut, int lut_stride,
