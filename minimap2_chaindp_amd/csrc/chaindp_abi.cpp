@@ -36,6 +36,7 @@ struct chaindp_ctx {
 	Unit *d_units = nullptr;
 	unsigned long long *d_counters = nullptr;
 	chaindp::PrepassScratch pre = {nullptr, nullptr, nullptr};
+	chaindp::CompactScratch cmp = {nullptr, nullptr, nullptr, nullptr};
 	uint16_t *d_lut = nullptr;
 	size_t lut_bytes = 0;
 	bool use_lut = true;
@@ -100,7 +101,7 @@ extern "C" void chaindp_destroy(chaindp_ctx_t *ctx)
 	if (ctx->stream) hipStreamSynchronize(ctx->stream);
 	for (auto &es : ctx->pending) for (int k = 0; k < es.n; ++k) hipEventDestroy(es.e[k]);
 	void *bufs[] = {ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_sumq, ctx->d_units,
-	                ctx->d_counters, ctx->pre.start_mask, ctx->pre.block_units, ctx->pre.block_singles, ctx->d_lut, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
+	                ctx->d_counters, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->d_lut, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
 	for (void *b : bufs) if (b) hipFree(b);
 	if (ctx->stream) hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -110,7 +111,10 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 {
 	int n_dev = 0;
 	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { g_create_error = "no HIP device visible"; return nullptr; }
-	if (device < 0 || device >= n_dev || max_anchors < 0 || max_reads < 0) { g_create_error = "bad device index or capacity"; return nullptr; }
+	if (device < 0 || device >= n_dev || max_anchors < 0 || max_reads < 0 || max_anchors > 0x7fffffff || max_reads > 0x7fffffff) {
+		g_create_error = "bad device index or capacity (at most 2^31-1 anchors and reads per batch)";
+		return nullptr;
+	}
 	chaindp_ctx *ctx = new chaindp_ctx();
 	ctx->device = device;
 	ctx->cap_anchors = max_anchors > 0 ? max_anchors : 1;
@@ -131,8 +135,8 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	size_t mask_bytes = 0, blocks_bytes = 0;
 	chaindp::prepass_scratch_bytes(ctx->cap_anchors, &mask_bytes, &blocks_bytes);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.start_mask, mask_bytes);
-	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.block_units, blocks_bytes);
-	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.block_singles, blocks_bytes);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.block_cnt, blocks_bytes);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.tile_tmp, blocks_bytes);
 	if (e != hipSuccess) {
 		g_create_error = std::string("chaindp_create: ") + hipGetErrorString(e);
 		chaindp_destroy(ctx);
@@ -297,6 +301,12 @@ static int compact_launch(chaindp_ctx *ctx, const chaindp_params_t *par)
 		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_id, na * 4));
 		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_seeds_off, (nr + 1) * 8));
 		HIP_TRY(ctx, hipMalloc(&ctx->d_seeds, na * sizeof(chaindp_seed_t)));
+		size_t flags_bytes = 0, blocks_bytes = 0;
+		chaindp::compact_scratch_bytes(ctx->cap_anchors, &flags_bytes, &blocks_bytes);
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->cmp.flags, flags_bytes));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->cmp.block_cnt, blocks_bytes));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->cmp.tile_tmp, blocks_bytes));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->cmp.n_seeds, 8));
 	}
 	EventSet es; es.n = 0; es.slot0 = 2;
 	if (ctx->prof) {
@@ -305,7 +315,7 @@ static int compact_launch(chaindp_ctx *ctx, const chaindp_params_t *par)
 		HIP_TRY(ctx, hipEventRecord(es.e[0], ctx->stream));
 	}
 	HIP_TRY(ctx, chaindp::launch_compact(ctx->stream, to_params(par), ctx->n_reads, ctx->total, ctx->d_off, ctx->d_a, ctx->d_f, ctx->d_p,
-	                                     ctx->d_v, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds, nullptr));
+	                                     ctx->d_v, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds, ctx->cmp));
 	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[1], ctx->stream)); ctx->pending.push_back(es); }
 	return CHAINDP_OK;
 }
@@ -420,10 +430,10 @@ extern "C" int chaindp_get_stats(chaindp_ctx_t *ctx, int64_t st[4])
 {
 	if (!ctx || !st) return CHAINDP_ERR_ARG;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	unsigned long long c[2] = {0, 0};
+	unsigned long long c = 0;
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
-	ctx->stats[0] = (int64_t)c[0]; ctx->stats[1] = (int64_t)c[1];
+	HIP_TRY(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+	ctx->stats[0] = (int64_t)(c & 0xffffffffull); ctx->stats[1] = (int64_t)(c >> 32);
 	for (int k = 0; k < 4; ++k) st[k] = ctx->stats[k];
 	return CHAINDP_OK;
 }

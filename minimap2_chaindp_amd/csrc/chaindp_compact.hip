@@ -1,4 +1,5 @@
-// chaindp_compact.hip -- f/p/v -> new_seed[] (reference chain.c:286-317) as parallel kernels.
+// chaindp_compact.hip -- f/p/v -> new_seed[] (reference chain.c:286-317) as anchor-parallel kernels, plus the
+// small multi-block scan both this stage and the prepass use.
 //
 // The reference compacts while it runs the recurrence, in anchor order:
 //   at step k: if p[k] >= 0 and p[k] has not been emitted yet, emit p[k] first ("late" emission,
@@ -7,155 +8,272 @@
 // emitted late, just before the FIRST later k with p[k] == i (if any).  Hence, per read:
 //   first_child[i] = min{k : p[k] == i}                      (only needed where !self(i))
 //   late(k)  = p[k] >= 0 && !self(p[k]) && first_child[p[k]] == k
-//   count(k) = late(k) + self(k)   in {0,1,2};   pos = exclusive prefix sum of count over the read
+//   count(k) = late(k) + self(k)   in {0,1,2};   pos = exclusive prefix sum of count
 //   id[p[k]] = pos[k] if late(k);  id[k] = pos[k] + late(k) if self(k)
 //   record of anchor i = { a[i], (id[p[i]] << 2 or -4) | (v[i] >= min_sc) | (f[i] < v[i]) << 1, f[i] }
-// (a late-emitted anchor has p < 0, so its record carries -4 | flags).  oracle/chain_oracle.c:co_compact
-// is the sequential statement of the same thing; tests compare the bytes.
+// (a late-emitted anchor has p < 0, so its record carries -4 | flags).  Because a read's records are
+// contiguous and reads follow each other, the prefix sum is taken over the whole batch and a read's
+// offset is the value at its first anchor: seeds_off[r] = pos[off[r]]; ids are made read-relative when
+// the records are written.  oracle/chain_oracle.c:co_compact is the sequential statement of the same thing;
+// tests compare the bytes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "chaindp_kernels.h"
 
 namespace chaindp {
 
-#define NO_CHILD 0x7f7f7f7f   // hipMemsetAsync(0x7f) pattern; larger than any read-relative index in use
-
 struct SeedRec { uint64_t x, y; int32_t p, f; };   // == struct new_seed (minimap.h:51-55)
+
+#define CMP_BLOCK 256
+#define CMP_PER_BLOCK 1024
 
 __device__ __forceinline__ bool self_emit(int32_t vi, int32_t pi, int min_sc) { return vi >= min_sc || pi >= 0; }
 
-// C2: first_child via atomicMin, one wave per read (grid-stride over reads)
-__global__ __launch_bounds__(256) void k_first_child(Params par, int64_t n_reads, const int64_t *__restrict__ off,
-                                                     const int32_t *__restrict__ p, const int32_t *__restrict__ v,
-                                                     int32_t *__restrict__ first_child)
+// largest r in [lo, hi] with off[r] <= g
+__device__ __forceinline__ int64_t read_of_c(const int64_t *__restrict__ off, int64_t lo, int64_t hi, int64_t g)
 {
-	const int lane = threadIdx.x & 63;
-	const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-	for (int64_t r = wave0; r < n_reads; r += n_waves) {
-		const int64_t rs = off[r], n = off[r + 1] - rs;
-		for (int64_t k = lane; k < n; k += 64) {
-			const int32_t q = p[rs + k];
-			if (q >= 0 && !self_emit(v[rs + q], p[rs + q], par.min_sc))
-				atomicMin(&first_child[rs + q], (int32_t)k);
-		}
+	while (lo < hi) {
+		const int64_t mid = (lo + hi + 1) >> 1;
+		if (off[mid] <= g) lo = mid; else hi = mid - 1;
 	}
+	return lo;
 }
 
-// C3: per-read positions.  Writes id[] and new_i[r] (into seeds_off[r+1], scanned by k_scan_reads).
-__global__ __launch_bounds__(256) void k_positions(Params par, int64_t n_reads, const int64_t *__restrict__ off,
-                                                   const int32_t *__restrict__ p, const int32_t *__restrict__ v,
-                                                   const int32_t *__restrict__ first_child, int32_t *__restrict__ id,
-                                                   int64_t *__restrict__ seeds_off)
+// reads touched by a block's anchor range, found once per block
+__device__ __forceinline__ void block_read_range(const int64_t *__restrict__ off, int64_t n_reads, int64_t g0, int64_t g1,
+                                                 int64_t &rlo, int64_t &rhi)
 {
-	const int lane = threadIdx.x & 63;
-	const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-	for (int64_t r = wave0; r < n_reads; r += n_waves) {
-		const int64_t rs = off[r], n = off[r + 1] - rs;
-		int carry = 0;
-		for (int64_t t0 = 0; t0 < n; t0 += 64) {
-			const int64_t k = t0 + lane;
-			bool late = false, self = false;
-			int32_t q = -1;
-			if (k < n) {
-				q = p[rs + k];
-				self = self_emit(v[rs + k], q, par.min_sc);
-				late = q >= 0 && !self_emit(v[rs + q], p[rs + q], par.min_sc) && first_child[rs + q] == (int32_t)k;
-			}
-			const int c = (int)late + (int)self;
-			// wave exclusive prefix sum of c (values 0..2): two ballots
-			const uint64_t b0 = __builtin_amdgcn_ballot_w64(c & 1), b1 = __builtin_amdgcn_ballot_w64(c & 2);
-			const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
-			const int pos = carry + __builtin_popcountll(b0 & below) + 2 * __builtin_popcountll(b1 & below);
-			if (late) id[rs + q] = pos;
-			if (self) id[rs + k] = pos + (int)late;
-			carry += __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1);
-		}
-		if (lane == 0) seeds_off[r + 1] = carry;
+	__shared__ int64_t s_r[2];
+	if (threadIdx.x == 0) {
+		s_r[0] = read_of_c(off, 0, n_reads - 1, g0);
+		s_r[1] = read_of_c(off, 0, n_reads - 1, g1 - 1);
 	}
+	__syncthreads();
+	rlo = s_r[0]; rhi = s_r[1];
 }
 
-// exclusive scan of new_i over reads, in place on seeds_off[1..n_reads] (seeds_off[0] = 0); single block
-__global__ __launch_bounds__(1024) void k_scan_reads(int64_t n_reads, int64_t *__restrict__ seeds_off)
+// ---------------------------------------------------------------- exclusive scan of uint64 items (3 small kernels)
+// Items are per-1024-anchor block counts (two 32-bit counters packed in one word), so even a 1 G anchor batch
+// is only 1 M items; level 1 scans tiles of 1024 items, level 2 the tile totals in a single block, level 3 adds.
+
+__global__ __launch_bounds__(256) void k_scan_l1(int64_t n, unsigned long long *__restrict__ data, unsigned long long *__restrict__ tile_tot)
 {
-	__shared__ int64_t part[1024];
+	__shared__ unsigned long long s_w[4];
+	const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+	unsigned long long v[4], sum = 0;
+	for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? data[base + k] : 0; sum += v[k]; }
+	unsigned long long incl = sum;
+	for (int d = 1; d < 64; d <<= 1) { const unsigned long long t = __shfl_up(incl, d, 64); if ((threadIdx.x & 63) >= d) incl += t; }
+	if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+	__syncthreads();
+	unsigned long long woff = 0;
+	for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += s_w[w];
+	unsigned long long ex = woff + incl - sum;
+	for (int k = 0; k < 4; ++k) { if (base + k < n) data[base + k] = ex; ex += v[k]; }
+	if (threadIdx.x == 255) tile_tot[blockIdx.x] = woff + incl;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_l2(int64_t n_tiles, unsigned long long *__restrict__ tile_tot, unsigned long long *__restrict__ total_out)
+{
+	__shared__ unsigned long long part[1024];
 	const int tid = threadIdx.x;
-	const int64_t per = (n_reads + 1023) / 1024;
-	const int64_t lo = (int64_t)tid * per, hi = lo + per < n_reads ? lo + per : n_reads;
-	int64_t s = 0;
-	for (int64_t r = lo; r < hi; ++r) s += seeds_off[r + 1];
+	const int64_t per = (n_tiles + 1023) / 1024;
+	const int64_t lo = (int64_t)tid * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+	unsigned long long s = 0;
+	for (int64_t k = lo; k < hi; ++k) s += tile_tot[k];
 	part[tid] = s;
 	__syncthreads();
 	if (tid == 0) {
-		int64_t acc = 0;
-		for (int k = 0; k < 1024; ++k) { const int64_t t = part[k]; part[k] = acc; acc += t; }
-		seeds_off[0] = 0;
+		unsigned long long acc = 0;
+		for (int k = 0; k < 1024; ++k) { const unsigned long long t = part[k]; part[k] = acc; acc += t; }
+		*total_out = acc;
 	}
 	__syncthreads();
-	int64_t acc = part[tid];
-	for (int64_t r = lo; r < hi; ++r) { acc += seeds_off[r + 1]; seeds_off[r + 1] = acc; }
+	unsigned long long acc = part[tid];
+	for (int64_t k = lo; k < hi; ++k) { const unsigned long long t = tile_tot[k]; tile_tot[k] = acc; acc += t; }
+}
+
+__global__ __launch_bounds__(256) void k_scan_l3(int64_t n, unsigned long long *__restrict__ data, const unsigned long long *__restrict__ tile_off)
+{
+	const unsigned long long add = tile_off[blockIdx.x];
+	const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+	for (int k = 0; k < 4; ++k) if (base + k < n) data[base + k] += add;
+}
+
+hipError_t launch_scan_u64(hipStream_t st, int64_t n, unsigned long long *d_data, unsigned long long *d_tile_tmp,
+                           unsigned long long *d_total)
+{
+	if (n <= 0) return hipMemsetAsync(d_total, 0, sizeof(unsigned long long), st);
+	const int64_t tiles = (n + 1023) / 1024;
+	hipLaunchKernelGGL(k_scan_l1, dim3((unsigned)tiles), dim3(256), 0, st, n, d_data, d_tile_tmp);
+	hipLaunchKernelGGL(k_scan_l2, dim3(1), dim3(1024), 0, st, tiles, d_tile_tmp, d_total);
+	if (tiles > 1) hipLaunchKernelGGL(k_scan_l3, dim3((unsigned)tiles), dim3(256), 0, st, n, d_data, d_tile_tmp);
+	return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- compaction
+
+#define NO_CHILD 0x7f7f7f7f   // hipMemsetAsync(0x7f) pattern; larger than any read-relative index in use
+
+// C1: first_child via atomicMin (only non-self predecessors, i.e. chain starts below min_sc, take atomics)
+__global__ __launch_bounds__(CMP_BLOCK) void k_first_child(Params par, int64_t n_reads, int64_t total,
+                                                           const int64_t *__restrict__ off, const int32_t *__restrict__ p,
+                                                           const int32_t *__restrict__ v, int32_t *__restrict__ first_child)
+{
+	const int64_t g0 = (int64_t)blockIdx.x * CMP_PER_BLOCK;
+	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
+	int64_t rlo, rhi;
+	block_read_range(off, n_reads, g0, g1, rlo, rhi);
+	for (int64_t g = g0 + threadIdx.x; g < g1; g += CMP_BLOCK) {
+		const int32_t q = p[g];
+		if (q < 0) continue;
+		const int64_t rs = off[rlo == rhi ? rlo : read_of_c(off, rlo, rhi, g)];
+		if (!self_emit(v[rs + q], p[rs + q], par.min_sc)) atomicMin(&first_child[rs + q], (int32_t)(g - rs));
+	}
+}
+
+// C2: per-anchor emission flags (bit0 late, bit1 self) and per-block record counts
+__global__ __launch_bounds__(CMP_BLOCK) void k_count(Params par, int64_t n_reads, int64_t total,
+                                                     const int64_t *__restrict__ off, const int32_t *__restrict__ p,
+                                                     const int32_t *__restrict__ v, const int32_t *__restrict__ first_child,
+                                                     uint8_t *__restrict__ flags, unsigned long long *__restrict__ block_cnt)
+{
+	__shared__ unsigned int s_cnt;
+	const int64_t g0 = (int64_t)blockIdx.x * CMP_PER_BLOCK;
+	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
+	int64_t rlo, rhi;
+	if (threadIdx.x == 0) s_cnt = 0;
+	block_read_range(off, n_reads, g0, g1, rlo, rhi);
+	unsigned int mine = 0;
+	for (int64_t g = g0 + threadIdx.x; g < g1; g += CMP_BLOCK) {
+		const int32_t q = p[g];
+		const bool self = self_emit(v[g], q, par.min_sc);
+		bool late = false;
+		if (q >= 0) {
+			const int64_t rs = off[rlo == rhi ? rlo : read_of_c(off, rlo, rhi, g)];
+			late = !self_emit(v[rs + q], p[rs + q], par.min_sc) && first_child[rs + q] == (int32_t)(g - rs);
+		}
+		flags[g] = (uint8_t)((int)late | ((int)self << 1));
+		mine += (unsigned int)late + (unsigned int)self;
+	}
+	for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d, 64);
+	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
+	__syncthreads();
+	if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_cnt;
+}
+
+// C3: positions.  block_base = exclusive scan of block_cnt.  Writes batch-global ids and seeds_off[r] at every
+// read's first anchor (empty reads in front of it share the value).
+__global__ __launch_bounds__(CMP_BLOCK) void k_positions(int64_t n_reads, int64_t total, const int64_t *__restrict__ off,
+                                                         const int32_t *__restrict__ p, const uint8_t *__restrict__ flags,
+                                                         const unsigned long long *__restrict__ block_base,
+                                                         int32_t *__restrict__ id, int64_t *__restrict__ seeds_off)
+{
+	__shared__ unsigned int s_w[4];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int64_t g0 = (int64_t)blockIdx.x * CMP_PER_BLOCK;
+	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
+	int64_t rlo, rhi;
+	block_read_range(off, n_reads, g0, g1, rlo, rhi);
+	unsigned int carry = (unsigned int)block_base[blockIdx.x];
+	for (int64_t gb = g0; gb < g1; gb += CMP_BLOCK) {
+		const int64_t g = gb + threadIdx.x;
+		const int fl = g < g1 ? flags[g] : 0;
+		const int c = (fl & 1) + (fl >> 1);
+		const uint64_t b0 = __builtin_amdgcn_ballot_w64(c & 1), b1 = __builtin_amdgcn_ballot_w64(c & 2);
+		const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+		const unsigned int in_wave = __builtin_popcountll(b0 & below) + 2 * __builtin_popcountll(b1 & below);
+		if (lane == 0) s_w[wave] = __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1);
+		__syncthreads();
+		unsigned int woff = 0, tot = 0;
+		for (int w = 0; w < 4; ++w) { const unsigned int t = s_w[w]; if (w < wave) woff += t; tot += t; }
+		const unsigned int pos = carry + woff + in_wave;
+		if (g < g1) {
+			const int64_t r = rlo == rhi ? rlo : read_of_c(off, rlo, rhi, g);
+			const int64_t rs = off[r];
+			if (fl & 1) id[rs + p[g]] = (int32_t)pos;
+			if (fl & 2) id[g] = (int32_t)(pos + (fl & 1));
+			if (g == rs) for (int64_t rr = r; rr >= 0 && off[rr] == rs; --rr) seeds_off[rr] = (int64_t)pos;
+		}
+		carry += tot;
+		__syncthreads();
+	}
+}
+
+// seeds_off of trailing empty reads and the end marker
+__global__ void k_finish_offsets(int64_t n_reads, int64_t total, const int64_t *__restrict__ off,
+                                 const unsigned long long *__restrict__ n_seeds, int64_t *__restrict__ seeds_off)
+{
+	const int64_t m = (int64_t)(uint32_t)*n_seeds;
+	seeds_off[n_reads] = m;
+	for (int64_t r = n_reads - 1; r >= 0 && off[r] == total; --r) seeds_off[r] = m;
 }
 
 // C4: records
-__global__ __launch_bounds__(256) void k_write_seeds(Params par, int64_t n_reads, const int64_t *__restrict__ off,
-                                                     const ulonglong2 *__restrict__ a, const int32_t *__restrict__ f,
-                                                     const int32_t *__restrict__ p, const int32_t *__restrict__ v,
-                                                     const int32_t *__restrict__ first_child, const int32_t *__restrict__ id,
-                                                     const int64_t *__restrict__ seeds_off, SeedRec *__restrict__ seeds)
+__global__ __launch_bounds__(CMP_BLOCK) void k_write_seeds(Params par, int64_t n_reads, int64_t total,
+                                                           const int64_t *__restrict__ off, const ulonglong2 *__restrict__ a,
+                                                           const int32_t *__restrict__ f, const int32_t *__restrict__ p,
+                                                           const int32_t *__restrict__ v, const uint8_t *__restrict__ flags,
+                                                           const int32_t *__restrict__ id, const int64_t *__restrict__ seeds_off,
+                                                           SeedRec *__restrict__ seeds)
 {
-	const int lane = threadIdx.x & 63;
-	const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+	const int64_t g0 = (int64_t)blockIdx.x * CMP_PER_BLOCK;
+	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
+	int64_t rlo, rhi;
+	block_read_range(off, n_reads, g0, g1, rlo, rhi);
 	const int min_sc = par.min_sc;
-	for (int64_t r = wave0; r < n_reads; r += n_waves) {
-		const int64_t rs = off[r], n = off[r + 1] - rs;
-		SeedRec *out = seeds + seeds_off[r];
-		for (int64_t k = lane; k < n; k += 64) {
-			const int32_t q = p[rs + k], vk = v[rs + k], fk = f[rs + k];
-			if (!self_emit(vk, q, min_sc)) continue;
-			const int32_t idk = id[rs + k];
-			int32_t pfield = (int32_t)(0xfffffffcu);                                         // (-1)<<2
-			if (q >= 0) {
-				const int32_t vq = v[rs + q], pq = p[rs + q], fq = f[rs + q];
-				if (!self_emit(vq, pq, min_sc) && first_child[rs + q] == (int32_t)k) {           // late emission of q, chain.c:292-302
-					const ulonglong2 aq = a[rs + q];
-					SeedRec rec;
-					rec.x = aq.x; rec.y = aq.y; rec.f = fq;
-					rec.p = (int32_t)(0xfffffffcu | (uint32_t)(vq >= min_sc) | ((uint32_t)(fq < vq) << 1));
-					out[idk - 1] = rec;
-				}
-				pfield = (int32_t)((uint32_t)id[rs + q] << 2);                                   // chain.c:310
+	for (int64_t g = g0 + threadIdx.x; g < g1; g += CMP_BLOCK) {
+		const int fl = flags[g];
+		if (!(fl & 2)) continue;                                                             // not emitted at its own step
+		const int64_t r = rlo == rhi ? rlo : read_of_c(off, rlo, rhi, g);
+		const int64_t rs = off[r];
+		const int32_t so = (int32_t)seeds_off[r];
+		const int32_t q = p[g], vk = v[g], fk = f[g], idk = id[g];
+		int32_t pfield = (int32_t)(0xfffffffcu);                                             // (-1)<<2
+		if (q >= 0) {
+			if (fl & 1) {                                                                    // late emission of q, chain.c:292-302
+				const int32_t vq = v[rs + q], fq = f[rs + q];
+				const ulonglong2 aq = a[rs + q];
+				SeedRec rec;
+				rec.x = aq.x; rec.y = aq.y; rec.f = fq;
+				rec.p = (int32_t)(0xfffffffcu | (uint32_t)(vq >= min_sc) | ((uint32_t)(fq < vq) << 1));
+				seeds[idk - 1] = rec;
 			}
-			const ulonglong2 ak = a[rs + k];
-			SeedRec rec;
-			rec.x = ak.x; rec.y = ak.y; rec.f = fk;
-			rec.p = pfield | (int32_t)(vk >= min_sc) | ((int32_t)(fk < vk) << 1);                // chain.c:313-314
-			out[idk] = rec;
+			pfield = (int32_t)((uint32_t)(id[rs + q] - so) << 2);                            // chain.c:310, read-relative index
 		}
+		const ulonglong2 ak = a[g];
+		SeedRec rec;
+		rec.x = ak.x; rec.y = ak.y; rec.f = fk;
+		rec.p = pfield | (int32_t)(vk >= min_sc) | ((int32_t)(fk < vk) << 1);                // chain.c:313-314
+		seeds[idk] = rec;
 	}
 }
 
-static inline unsigned grid_for_reads(int64_t n_reads)
+size_t compact_scratch_bytes(int64_t max_anchors, size_t *flags_bytes, size_t *blocks_bytes)
 {
-	int64_t blocks = (n_reads + 3) / 4;
-	if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
-	return (unsigned)(blocks < 1 ? 1 : blocks);
+	const size_t blocks = (size_t)(max_anchors + CMP_PER_BLOCK - 1) / CMP_PER_BLOCK;
+	*flags_bytes = ((size_t)max_anchors + 15) & ~(size_t)15;
+	*blocks_bytes = (blocks + 1) * 8;
+	return *flags_bytes + 2 * *blocks_bytes + 8;
 }
 
 hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off,
                           const void *d_a, const int32_t *d_f, const int32_t *d_p, const int32_t *d_v,
-                          int32_t *d_first_child, int32_t *d_id, int64_t *d_seeds_off, void *d_seeds, void *)
+                          int32_t *d_first_child, int32_t *d_id, int64_t *d_seeds_off, void *d_seeds, CompactScratch sc)
 {
 	hipError_t e;
 	if (n_reads <= 0) return hipMemsetAsync(d_seeds_off, 0, sizeof(int64_t), st);
-	if (total > 0 && (e = hipMemsetAsync(d_first_child, 0x7f, (size_t)total * 4, st)) != hipSuccess) return e;
-	const unsigned g = grid_for_reads(n_reads);
-	hipLaunchKernelGGL(k_first_child, dim3(g), dim3(256), 0, st, par, n_reads, d_off, d_p, d_v, d_first_child);
-	hipLaunchKernelGGL(k_positions, dim3(g), dim3(256), 0, st, par, n_reads, d_off, d_p, d_v, d_first_child, d_id, d_seeds_off);
-	hipLaunchKernelGGL(k_scan_reads, dim3(1), dim3(1024), 0, st, n_reads, d_seeds_off);
-	hipLaunchKernelGGL(k_write_seeds, dim3(g), dim3(256), 0, st, par, n_reads, d_off, (const ulonglong2*)d_a, d_f, d_p, d_v,
-	                   d_first_child, d_id, d_seeds_off, (SeedRec*)d_seeds);
+	if (total <= 0) return hipMemsetAsync(d_seeds_off, 0, (size_t)(n_reads + 1) * sizeof(int64_t), st);
+	if ((e = hipMemsetAsync(d_first_child, 0x7f, (size_t)total * 4, st)) != hipSuccess) return e;
+	const int64_t blocks = (total + CMP_PER_BLOCK - 1) / CMP_PER_BLOCK;
+	const dim3 g((unsigned)blocks), b(CMP_BLOCK);
+	hipLaunchKernelGGL(k_first_child, g, b, 0, st, par, n_reads, total, d_off, d_p, d_v, d_first_child);
+	hipLaunchKernelGGL(k_count, g, b, 0, st, par, n_reads, total, d_off, d_p, d_v, d_first_child, sc.flags, sc.block_cnt);
+	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, sc.n_seeds)) != hipSuccess) return e;
+	hipLaunchKernelGGL(k_positions, g, b, 0, st, n_reads, total, d_off, d_p, sc.flags, sc.block_cnt, d_id, d_seeds_off);
+	hipLaunchKernelGGL(k_finish_offsets, dim3(1), dim3(1), 0, st, n_reads, total, d_off, sc.n_seeds, d_seeds_off);
+	hipLaunchKernelGGL(k_write_seeds, g, b, 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a, d_f, d_p, d_v, sc.flags, d_id,
+	                   d_seeds_off, (SeedRec*)d_seeds);
 	return hipGetLastError();
 }
 

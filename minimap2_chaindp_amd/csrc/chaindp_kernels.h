@@ -22,11 +22,12 @@ struct Unit {
 // prepass scratch: one 64-bit unit-start mask per 64 anchors, per-block unit / singleton counts
 struct PrepassScratch {
 	uint64_t *start_mask;
-	uint32_t *block_units, *block_singles;
+	unsigned long long *block_cnt;   // per 1024-anchor block: units | singletons << 32; scanned in place
+	unsigned long long *tile_tmp;    // scratch of the scan
 };
 size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *blocks_bytes);
 
-// counters[0] = number of units emitted, counters[1] = singleton anchors resolved by the prepass
+// counters[0] = units emitted (low 32 bits) | singleton anchors resolved by the prepass (high 32 bits)
 hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off, const void *d_a,
                           unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
                           int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg);
@@ -43,11 +44,22 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
                         const Unit *d_units, const unsigned long long *d_counters,
                         int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg);
 
+// exclusive scan of n uint64 items in place (d_tile_tmp: ceil(n/1024)+1 words), total to *d_total
+hipError_t launch_scan_u64(hipStream_t st, int64_t n, unsigned long long *d_data, unsigned long long *d_tile_tmp,
+                           unsigned long long *d_total);
+
 // compaction into new_seed[] (reference chain.c:286-317): see chaindp_compact.hip
+struct CompactScratch {
+	uint8_t *flags;                  // per anchor: bit0 late, bit1 self
+	unsigned long long *block_cnt;   // per 1024-anchor block record count; scanned in place
+	unsigned long long *tile_tmp;
+	unsigned long long *n_seeds;     // total records of the batch
+};
+size_t compact_scratch_bytes(int64_t max_anchors, size_t *flags_bytes, size_t *blocks_bytes);
 hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off,
                           const void *d_a, const int32_t *d_f, const int32_t *d_p, const int32_t *d_v,
                           int32_t *d_first_child, int32_t *d_id, int64_t *d_seeds_off, void *d_seeds,
-                          void *d_scan_tmp);
+                          CompactScratch sc);
 
 } // namespace chaindp
 #endif

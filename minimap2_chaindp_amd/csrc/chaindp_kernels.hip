@@ -118,7 +118,7 @@ __device__ __forceinline__ int seg_of_hi(uint32_t yhi) { return (int)((yhi >> 16
 //               global mark, and the block writes: a 64-bit unit-start mask per wave-tile, its unit and
 //               singleton counts, and ONE integer atomic per (block, read) for the q_span sum
 //               (order-independent, so deterministic).
-// k_scan_blocks: exclusive scan of the per-block unit counts (single block) -> counters[0..1].
+// launch_scan_u64: exclusive scan of the per-block (units | singletons << 32) counts -> counters[0].
 // k_emit_units: one thread per mask word; writes the Unit records in anchor order (deterministic).
 // A single same-address atomic per wave would cap this stage at ~90 atomics/us (measured: 9 ms for
 // 76 M anchors), hence count -> scan -> emit.
@@ -140,7 +140,7 @@ __device__ __forceinline__ int64_t read_of(const int64_t *__restrict__ off, int6
 __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_reads, int64_t total,
                                                        const int64_t *__restrict__ off, const ulonglong2 *__restrict__ a,
                                                        unsigned long long *__restrict__ sumq, uint64_t *__restrict__ start_mask,
-                                                       uint32_t *__restrict__ block_units, uint32_t *__restrict__ block_singles,
+                                                       unsigned long long *__restrict__ block_cnt,
                                                        int32_t *__restrict__ f, int32_t *__restrict__ p, int32_t *__restrict__ v,
                                                        int32_t *__restrict__ tg)
 {
@@ -202,44 +202,20 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_rea
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		if (one_read && s_sum) atomicAdd(&sumq[rlo], (unsigned long long)s_sum);
-		block_units[blockIdx.x] = s_units;
-		block_singles[blockIdx.x] = s_singles;
+		block_cnt[blockIdx.x] = (unsigned long long)s_singles << 32 | s_units;   // two counters, one scan
 	}
-}
-
-// in place: block_units[b] <- exclusive prefix sum; counters[0] <- total units, counters[1] <- total singletons
-__global__ __launch_bounds__(1024) void k_scan_blocks(int64_t n_blocks, uint32_t *__restrict__ block_units,
-                                                      const uint32_t *__restrict__ block_singles,
-                                                      unsigned long long *__restrict__ counters)
-{
-	__shared__ unsigned long long part[1024], part_s[1024];
-	const int tid = threadIdx.x;
-	const int64_t per = (n_blocks + 1023) / 1024;
-	const int64_t lo = (int64_t)tid * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
-	unsigned long long s = 0, ss = 0;
-	for (int64_t b = lo; b < hi; ++b) { s += block_units[b]; ss += block_singles[b]; }
-	part[tid] = s; part_s[tid] = ss;
-	__syncthreads();
-	if (tid == 0) {
-		unsigned long long acc = 0, acc_s = 0;
-		for (int k = 0; k < 1024; ++k) { const unsigned long long t = part[k]; part[k] = acc; acc += t; acc_s += part_s[k]; }
-		counters[0] = acc; counters[1] = acc_s;
-	}
-	__syncthreads();
-	unsigned long long acc = part[tid];
-	for (int64_t b = lo; b < hi; ++b) { const uint32_t t = block_units[b]; block_units[b] = (uint32_t)acc; acc += t; }
 }
 
 __global__ __launch_bounds__(256) void k_emit_units(int64_t n_reads, int64_t n_words, const int64_t *__restrict__ off,
                                                     const uint64_t *__restrict__ start_mask,
-                                                    const uint32_t *__restrict__ block_base, Unit *__restrict__ units)
+                                                    const unsigned long long *__restrict__ block_base, Unit *__restrict__ units)
 {
 	const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (w >= n_words) return;
 	uint64_t m = start_mask[w];
 	if (!m) return;
 	const int64_t b = w / PRE_WORDS;
-	uint64_t pos = block_base[b];
+	uint64_t pos = (uint32_t)block_base[b];                 // low word: units before this block
 	for (int64_t k = b * PRE_WORDS; k < w; ++k) pos += (uint64_t)__builtin_popcountll(start_mask[k]);
 	int64_t r = read_of(off, 0, n_reads - 1, w << 6);
 	while (m) {
@@ -600,7 +576,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 	const bool x32_ok = ((uint64_t)(int64_t)par.max_dist_x + 1) * (uint64_t)(RING + 1) < (1ull << 32);
 	const int lane = threadIdx.x;
 
-	for (int64_t ub = blockIdx.x; ub < (int64_t)counters[0]; ub += gridDim.x) {
+	const int64_t n_units = (int64_t)(uint32_t)counters[0];       // low word: units, high word: singletons (prepass)
+	for (int64_t ub = blockIdx.x; ub < n_units; ub += gridDim.x) {
 		const Unit u = units[ub];
 		const int64_t rs = off[u.read], re = off[u.read + 1];
 		const unsigned long long sq = sumq[u.read];
@@ -637,10 +614,10 @@ hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, in
 	const int64_t blocks = (total + PRE_PER_BLOCK - 1) / PRE_PER_BLOCK;
 	const int64_t words = (total + 63) / 64;
 	hipLaunchKernelGGL(k_prepass, dim3((unsigned)blocks), dim3(PRE_BLOCK), 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a,
-	                   d_sumq, sc.start_mask, sc.block_units, sc.block_singles, d_f, d_p, d_v, d_tg);
-	hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, blocks, sc.block_units, sc.block_singles, d_counters);
+	                   d_sumq, sc.start_mask, sc.block_cnt, d_f, d_p, d_v, d_tg);
+	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, d_counters)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_emit_units, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, n_reads, words, d_off,
-	                   sc.start_mask, sc.block_units, d_units);
+	                   sc.start_mask, sc.block_cnt, d_units);
 	return hipGetLastError();
 }
 
@@ -648,7 +625,7 @@ size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *bl
 {
 	const size_t words = (size_t)(max_anchors + 63) / 64, blocks = (size_t)(max_anchors + PRE_PER_BLOCK - 1) / PRE_PER_BLOCK;
 	*mask_bytes = (words + 1) * 8;
-	*blocks_bytes = (blocks + 1) * 4;
+	*blocks_bytes = (blocks + 1) * 8;
 	return *mask_bytes + 2 * *blocks_bytes;
 }
 
