@@ -98,6 +98,17 @@ int chaindp_upload_gather(chaindp_ctx_t *ctx, int64_t n_reads, const int64_t *of
 int chaindp_compact_offsets(chaindp_ctx_t *ctx, const chaindp_params_t *par, int64_t *seeds_off);
 int chaindp_download_seeds(chaindp_ctx_t *ctx, int64_t first_seed, int64_t n_seeds, chaindp_seed_t *dst);
 
+/* The same two steps for callers whose per-read buffers are PINNED, device-visible host memory
+ * (chaindp_host_alloc / hipHostMalloc): one kernel per direction streams every read between its host
+ * buffer and HBM, with no per-read copy call and no host-side staging.  pinned = 1 in
+ * chaindp_upload_gather_ex selects it (pinned = 0 behaves like chaindp_upload_gather).
+ * chaindp_scatter_seeds writes read r's new_seed[] (after chaindp_compact_offsets) to dst[r] and zero-fills
+ * up to the next 64-byte boundary, the padding of the reference's result packets (map.c:543-545); dst[r] ==
+ * NULL skips the read.  Asynchronous: chaindp_sync() before reading dst. */
+int chaindp_upload_gather_ex(chaindp_ctx_t *ctx, int64_t n_reads, const int64_t *off,
+                             const chaindp_anchor_t *const *read_anchors, const int32_t *n_segs_per_read, int pinned);
+int chaindp_scatter_seeds(chaindp_ctx_t *ctx, int64_t n_reads, chaindp_seed_t *const *dst);
+
 /* Pinned host memory (hipHostMalloc) for callers that want DMA-able staging buffers. */
 void *chaindp_host_alloc(size_t bytes);
 void chaindp_host_free(void *p);

@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     "chaindp_upload", "chaindp_run", "chaindp_sync", "chaindp_download", "chaindp_compact",
     "chaindp_upload_gather", "chaindp_compact_offsets", "chaindp_download_seeds", "chaindp_host_alloc",
     "chaindp_host_free", "chaindp_run_device", "chaindp_set_profiling", "chaindp_get_kernel_ms",
-    "chaindp_get_stats", "chaindp_set_ring", "chaindp_run_full", "chaindp_set_variant",
+    "chaindp_get_stats", "chaindp_set_ring", "chaindp_run_full", "chaindp_set_variant", "chaindp_upload_gather_ex", "chaindp_scatter_seeds",
 )
 
 

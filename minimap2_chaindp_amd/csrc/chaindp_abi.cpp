@@ -38,6 +38,8 @@ struct chaindp_ctx {
 	chaindp::PrepassScratch pre = {nullptr, nullptr, nullptr};
 	chaindp::CompactScratch cmp = {nullptr, nullptr, nullptr, nullptr};
 	uint16_t *d_lut = nullptr;
+	void **d_ptrs = nullptr;         // per-read host pointers for the gather / scatter kernels
+	size_t ptr_cap = 0;
 	size_t lut_bytes = 0;
 	bool use_lut = true;
 	// compaction (allocated on first use)
@@ -101,7 +103,7 @@ extern "C" void chaindp_destroy(chaindp_ctx_t *ctx)
 	if (ctx->stream) hipStreamSynchronize(ctx->stream);
 	for (auto &es : ctx->pending) for (int k = 0; k < es.n; ++k) hipEventDestroy(es.e[k]);
 	void *bufs[] = {ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_sumq, ctx->d_units,
-	                ctx->d_counters, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->d_lut, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
+	                ctx->d_counters, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
 	for (void *b : bufs) if (b) hipFree(b);
 	if (ctx->stream) hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -367,6 +369,58 @@ extern "C" int chaindp_compact(chaindp_ctx_t *ctx, const chaindp_params_t *par, 
 	if (rc) return rc;
 	if ((rc = chaindp_download_seeds(ctx, 0, ctx->n_seeds, seeds)) != CHAINDP_OK) return rc;
 	return chaindp_sync(ctx);
+}
+
+// device array of n_reads host pointers (grown on demand)
+static int stage_pointers(chaindp_ctx *ctx, const void *const *ptrs, int64_t n)
+{
+	if ((size_t)n > ctx->ptr_cap) {
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		if (ctx->d_ptrs) HIP_TRY(ctx, hipFree(ctx->d_ptrs));
+		ctx->d_ptrs = nullptr; ctx->ptr_cap = 0;
+		const size_t cap = (size_t)n + (size_t)n / 2 + 64;
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ptrs, cap * sizeof(void*)));
+		ctx->ptr_cap = cap;
+	}
+	if (n) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ptrs, ptrs, (size_t)n * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_upload_gather_ex(chaindp_ctx_t *ctx, int64_t n_reads, const int64_t *off,
+                                        const chaindp_anchor_t *const *read_anchors, const int32_t *n_segs_per_read, int pinned)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	if (!pinned) return chaindp_upload_gather(ctx, n_reads, off, read_anchors, n_segs_per_read);
+	if (n_reads < 0 || !off || (n_reads > 0 && (off[0] != 0 || !read_anchors))) { ctx->err = "bad offsets"; return CHAINDP_ERR_ARG; }
+	const int64_t total = n_reads > 0 ? off[n_reads] : 0;
+	if (n_reads > ctx->cap_reads || total > ctx->cap_anchors) {
+		ctx->err = "batch exceeds the capacity the context was created with";
+		return CHAINDP_ERR_CAPACITY;
+	}
+	for (int64_t r = 0; r < n_reads; ++r)
+		if (off[r + 1] < off[r] || (off[r + 1] > off[r] && !read_anchors[r])) { ctx->err = "bad read in gather list"; return CHAINDP_ERR_ARG; }
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+	int rc = stage_pointers(ctx, (const void *const *)read_anchors, n_reads);
+	if (rc) return rc;
+	HIP_TRY(ctx, chaindp::launch_gather_reads(ctx->stream, n_reads, ctx->d_off, (const void *const *)ctx->d_ptrs, ctx->d_a));
+	ctx->has_n_segs = n_segs_per_read != nullptr;
+	if (n_segs_per_read && n_reads)
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_n_segs, n_segs_per_read, (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // the host arrays (off, pointers) may go away after the call
+	ctx->n_reads = n_reads; ctx->total = total; ctx->ran = false;
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_scatter_seeds(chaindp_ctx_t *ctx, int64_t n_reads, chaindp_seed_t *const *dst)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	if (n_reads != ctx->n_reads || (n_reads > 0 && !dst) || !ctx->d_seeds) { ctx->err = "scatter does not match the last compaction"; return CHAINDP_ERR_ARG; }
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc = stage_pointers(ctx, (const void *const *)dst, n_reads);
+	if (rc) return rc;
+	HIP_TRY(ctx, chaindp::launch_scatter_seeds(ctx->stream, n_reads, ctx->d_seeds_off, (void *const *)ctx->d_ptrs, ctx->d_seeds));
+	return CHAINDP_OK;
 }
 
 extern "C" int chaindp_upload_gather(chaindp_ctx_t *ctx, int64_t n_reads, const int64_t *off,

@@ -1,0 +1,56 @@
+// chaindp_io.hip -- zero-copy movement between pinned host packet buffers and HBM.
+//
+// The packet shim's reads sit in separate pinned (hipHostMalloc, device-visible) buffers.  Issuing one
+// hipMemcpyAsync per read costs ~5 us each (thousands per batch), and copying results once more on the host
+// costs a core; instead one kernel per direction moves all reads of a batch: each workgroup streams one read
+// between its host buffer and its CSR slot in HBM with 16-byte (anchors) / 8-byte (24-byte records) lanes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "chaindp_kernels.h"
+
+namespace chaindp {
+
+// d_a[off[r] .. off[r+1]) <- src[r][0 .. n_r)      (src[r]: device-visible host pointer)
+__global__ __launch_bounds__(256) void k_gather_reads(int64_t n_reads, const int64_t *__restrict__ off,
+                                                      const ulonglong2 *const *__restrict__ src, ulonglong2 *__restrict__ d_a)
+{
+	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+		const int64_t o = off[r], n = off[r + 1] - o;
+		const ulonglong2 *s = src[r];
+		for (int64_t k = threadIdx.x; k < n; k += blockDim.x) d_a[o + k] = s[k];
+	}
+}
+
+// dst[r][0 .. n_r*3) (8-byte words) <- seeds[seeds_off[r] .. seeds_off[r+1]); then zero up to the next 64-byte boundary
+__global__ __launch_bounds__(256) void k_scatter_seeds(int64_t n_reads, const int64_t *__restrict__ seeds_off,
+                                                       unsigned long long *const *__restrict__ dst,
+                                                       const unsigned long long *__restrict__ seeds)
+{
+	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+		unsigned long long *d = dst[r];
+		if (!d) continue;
+		const int64_t w0 = seeds_off[r] * 3, nw = (seeds_off[r + 1] - seeds_off[r]) * 3;      // 24 B = 3 words
+		const int64_t nw_pad = ((nw * 8 + 63) & ~(int64_t)63) >> 3;
+		for (int64_t k = threadIdx.x; k < nw_pad; k += blockDim.x) d[k] = k < nw ? seeds[w0 + k] : 0ull;
+	}
+}
+
+hipError_t launch_gather_reads(hipStream_t st, int64_t n_reads, const int64_t *d_off, const void *const *d_src, void *d_a)
+{
+	if (n_reads <= 0) return hipSuccess;
+	const int64_t blocks = n_reads < 65535 ? n_reads : 65535;
+	hipLaunchKernelGGL(k_gather_reads, dim3((unsigned)blocks), dim3(256), 0, st, n_reads, d_off,
+	                   (const ulonglong2 *const *)d_src, (ulonglong2*)d_a);
+	return hipGetLastError();
+}
+
+hipError_t launch_scatter_seeds(hipStream_t st, int64_t n_reads, const int64_t *d_seeds_off, void *const *d_dst, const void *d_seeds)
+{
+	if (n_reads <= 0) return hipSuccess;
+	const int64_t blocks = n_reads < 65535 ? n_reads : 65535;
+	hipLaunchKernelGGL(k_scatter_seeds, dim3((unsigned)blocks), dim3(256), 0, st, n_reads, d_seeds_off,
+	                   (unsigned long long *const *)d_dst, (const unsigned long long*)d_seeds);
+	return hipGetLastError();
+}
+
+} // namespace chaindp

@@ -61,5 +61,9 @@ hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, in
                           int32_t *d_first_child, int32_t *d_id, int64_t *d_seeds_off, void *d_seeds,
                           CompactScratch sc);
 
+// zero-copy movement between device-visible (pinned) host buffers and HBM: chaindp_io.hip
+hipError_t launch_gather_reads(hipStream_t st, int64_t n_reads, const int64_t *d_off, const void *const *d_src, void *d_a);
+hipError_t launch_scatter_seeds(hipStream_t st, int64_t n_reads, const int64_t *d_seeds_off, void *const *d_dst, const void *d_seeds);
+
 } // namespace chaindp
 #endif

@@ -4,9 +4,9 @@
 // Structure: producers (the reference's worker threads, map.c:439-444) obtain pinned packet buffers
 // and submit them; one service thread per GPU drains the submit queue, merges up to
 // max_packets_per_batch packets into ONE device batch (reads grouped by their (gap_ref, gap_qry)
-// pair, which is uniform in practice), uploads each read's anchors straight from its pinned packet,
-// runs prepass + chain DP + compaction, and DMA-writes every read's new_seed[] straight into its
-// slot of a pinned result packet; the single consumer (recv_task_thread, fpga_chaindp.c:228) blocks
+// pair, which is uniform in practice), pulls every read's anchors straight out of the pinned packets
+// with one gather kernel, runs prepass + chain DP + compaction, and has one scatter kernel write every
+// read's new_seed[] straight into its slot of a pinned result packet (no host-side bulk copies); the single consumer (recv_task_thread, fpga_chaindp.c:228) blocks
 // in fpga_get_retbuf.  Results may return in any order (map.c:930,946 match by read_id).
 #include <hip/hip_runtime.h>
 #include <pthread.h>
@@ -149,16 +149,64 @@ void service_loop(int device)
 				reads.push_back(rr);
 			}
 		}
-		// ---- group by (gap_ref, gap_qry): one device batch per distinct pair
+		// ---- group by (gap_ref, gap_qry): one device batch per distinct pair (one pair in practice)
 		std::map<std::pair<int, int>, std::vector<size_t>> groups;
 		for (size_t r = 0; r < reads.size(); ++r)
 			if (reads[r].on_device) groups[{reads[r].task->gap_ref, reads[r].task->gap_qry}].push_back(r);
-		// Result packets can only be laid out once every read's new_i is known, and the device holds one
-		// group's results at a time, so each group's new_seed[] is staged in pinned memory first.
+		const bool single_group = groups.size() <= 1;
 		std::vector<int64_t> n_a(reads.size(), 0);
+		std::vector<const chaindp_seed_t*> seed_src(reads.size(), nullptr);   // multi-group only: staged new_seed[]
 		std::vector<void*> group_stage;
-		std::vector<std::vector<int64_t>> group_off;
-		std::vector<const std::vector<size_t>*> group_reads;
+		std::vector<Result> out;
+		std::vector<chaindp_seed_t*> seed_dst(reads.size(), nullptr);         // where each read's records go in its result packet
+		int64_t n_reads_done = 0, n_anchors_done = 0, n_err = 0;
+
+		// lays out the result packets (map.c:494-567 writes them the same way; parsed at map.c:918-931):
+		// headers are written by the host, the new_seed[] payload either by the device (single group: the
+		// scatter kernel writes straight into the pinned packet) or copied from a staging buffer.
+		auto build_packets = [&]() {
+			size_t r0 = 0;
+			for (size_t k = 0; k < pk.size(); ++k) {
+				const chaindp_pkt_hdr_t *h = (const chaindp_pkt_hdr_t*)pk[k].buf;
+				size_t bytes = sizeof(chaindp_pkt_hdr_t);
+				for (int i = 0; i < (int)h->num; ++i) {
+					bytes += sizeof(chaindp_pkt_result_t);
+					if (reads[r0 + i].on_device) bytes += CHAINDP_ALIGN64((uint64_t)n_a[r0 + i] * sizeof(chaindp_seed_t));
+				}
+				char *ob = (char*)g.pool.get(bytes);
+				if (!ob) fail_hard("out of pinned memory");
+				chaindp_pkt_hdr_t *oh = (chaindp_pkt_hdr_t*)ob;
+				memset(oh, 0, sizeof(*oh));
+				oh->magic = h->magic; oh->size = (uint32_t)bytes; oh->tid = h->tid; oh->num = h->num; oh->type = h->type; oh->lat = h->lat;
+				char *q = ob + sizeof(chaindp_pkt_hdr_t);
+				for (int i = 0; i < (int)h->num; ++i) {
+					const ReadRef &rr = reads[r0 + i];
+					chaindp_pkt_result_t *res = (chaindp_pkt_result_t*)q;
+					memset(res, 0, sizeof(*res));
+					res->read_id = rr.task->read_id;
+					q += sizeof(chaindp_pkt_result_t);
+					if (!rr.on_device) {
+						res->err_flag = 1; res->sub_size = sizeof(chaindp_pkt_result_t);   // header only (map.c:970-971)
+						++n_err;
+					} else {
+						const uint64_t sb = (uint64_t)n_a[r0 + i] * sizeof(chaindp_seed_t), sp = CHAINDP_ALIGN64(sb);
+						res->n_a = (uint32_t)n_a[r0 + i];
+						res->sub_size = (uint32_t)(sizeof(chaindp_pkt_result_t) + sp);
+						seed_dst[r0 + i] = (chaindp_seed_t*)q;
+						if (seed_src[r0 + i]) {
+							if (sb) memcpy(q, seed_src[r0 + i], sb);
+							if (sp > sb) memset(q + sb, 0, sp - sb);
+						}
+						q += sp;
+						n_anchors_done += rr.task->seednum;
+					}
+					++n_reads_done;
+				}
+				r0 += h->num;
+				out.push_back(Result{ob, (int)bytes});
+			}
+		};
+
 		for (auto &kv : groups) {
 			const std::vector<size_t> &idx = kv.second;
 			chaindp_params_t par;
@@ -174,69 +222,32 @@ void service_loop(int device)
 				nseg[k] = rr.task->n_segs;
 			}
 			std::vector<int64_t> soff(idx.size() + 1, 0);
-			int rc = chaindp_upload_gather(ctx, (int64_t)idx.size(), off.data(), ptrs.data(), nseg.data());
+			// the packets are pinned driver buffers: one gather kernel pulls every read's anchors over PCIe
+			int rc = chaindp_upload_gather_ex(ctx, (int64_t)idx.size(), off.data(), ptrs.data(), nseg.data(), 1);
 			if (rc == CHAINDP_OK) rc = chaindp_run(ctx, &par);
 			if (rc == CHAINDP_OK) rc = chaindp_compact_offsets(ctx, &par, soff.data());
-			void *stage = nullptr;
-			if (rc == CHAINDP_OK) {
+			if (rc != CHAINDP_OK) { fprintf(stderr, "[chaindp-fpga] %s\n", chaindp_last_error(ctx)); fail_hard("device batch failed"); }
+			for (size_t k = 0; k < idx.size(); ++k) n_a[idx[k]] = soff[k + 1] - soff[k];
+			if (single_group) {
+				build_packets();
+				std::vector<chaindp_seed_t*> dst(idx.size());
+				for (size_t k = 0; k < idx.size(); ++k) dst[k] = seed_dst[idx[k]];
+				rc = chaindp_scatter_seeds(ctx, (int64_t)idx.size(), dst.data());      // device writes into the result packets
+				if (rc == CHAINDP_OK) rc = chaindp_sync(ctx);
+			} else {
 				const int64_t m = soff[idx.size()];
-				stage = g.pool.get((size_t)(m > 0 ? m : 1) * sizeof(chaindp_seed_t));
+				void *stage = g.pool.get((size_t)(m > 0 ? m : 1) * sizeof(chaindp_seed_t));
 				if (!stage) fail_hard("out of pinned memory");
 				rc = chaindp_download_seeds(ctx, 0, m, (chaindp_seed_t*)stage);
 				if (rc == CHAINDP_OK) rc = chaindp_sync(ctx);
+				for (size_t k = 0; k < idx.size(); ++k) seed_src[idx[k]] = (const chaindp_seed_t*)stage + soff[k];
+				group_stage.push_back(stage);
 			}
 			if (rc != CHAINDP_OK) { fprintf(stderr, "[chaindp-fpga] %s\n", chaindp_last_error(ctx)); fail_hard("device batch failed"); }
-			for (size_t k = 0; k < idx.size(); ++k) n_a[idx[k]] = soff[k + 1] - soff[k];
-			group_stage.push_back(stage); group_off.push_back(std::move(soff)); group_reads.push_back(&idx);
 			std::lock_guard<std::mutex> lk(g.mu);
 			g.stats[3] += 1;
 		}
-		// where each read's seeds sit in its group's staging buffer
-		std::vector<const chaindp_seed_t*> seed_src(reads.size(), nullptr);
-		for (size_t gi = 0; gi < group_reads.size(); ++gi)
-			for (size_t k = 0; k < group_reads[gi]->size(); ++k)
-				seed_src[(*group_reads[gi])[k]] = (const chaindp_seed_t*)group_stage[gi] + group_off[gi][k];
-		// ---- result packets (map.c:494-567 writes them the same way; parsed at map.c:918-931)
-		size_t r0 = 0;
-		int64_t n_reads_done = 0, n_anchors_done = 0, n_err = 0;
-		std::vector<Result> out;
-		for (size_t k = 0; k < pk.size(); ++k) {
-			const chaindp_pkt_hdr_t *h = (const chaindp_pkt_hdr_t*)pk[k].buf;
-			size_t bytes = sizeof(chaindp_pkt_hdr_t);
-			for (int i = 0; i < (int)h->num; ++i) {
-				const ReadRef &rr = reads[r0 + i];
-				bytes += sizeof(chaindp_pkt_result_t);
-				if (rr.on_device) bytes += CHAINDP_ALIGN64((uint64_t)n_a[r0 + i] * sizeof(chaindp_seed_t));
-			}
-			char *ob = (char*)g.pool.get(bytes);
-			if (!ob) fail_hard("out of pinned memory");
-			chaindp_pkt_hdr_t *oh = (chaindp_pkt_hdr_t*)ob;
-			memset(oh, 0, sizeof(*oh));
-			oh->magic = h->magic; oh->size = (uint32_t)bytes; oh->tid = h->tid; oh->num = h->num; oh->type = h->type; oh->lat = h->lat;
-			char *q = ob + sizeof(chaindp_pkt_hdr_t);
-			for (int i = 0; i < (int)h->num; ++i) {
-				const ReadRef &rr = reads[r0 + i];
-				chaindp_pkt_result_t *res = (chaindp_pkt_result_t*)q;
-				memset(res, 0, sizeof(*res));
-				res->read_id = rr.task->read_id;
-				q += sizeof(chaindp_pkt_result_t);
-				if (!rr.on_device) {
-					res->err_flag = 1; res->sub_size = sizeof(chaindp_pkt_result_t);   // header only (map.c:970-971)
-					++n_err;
-				} else {
-					const uint64_t sb = (uint64_t)n_a[r0 + i] * sizeof(chaindp_seed_t), sp = CHAINDP_ALIGN64(sb);
-					res->n_a = (uint32_t)n_a[r0 + i];
-					res->sub_size = (uint32_t)(sizeof(chaindp_pkt_result_t) + sp);
-					if (sb) memcpy(q, seed_src[r0 + i], sb);
-					if (sp > sb) memset(q + sb, 0, sp - sb);
-					q += sp;
-					n_anchors_done += rr.task->seednum;
-				}
-				++n_reads_done;
-			}
-			r0 += h->num;
-			out.push_back(Result{ob, (int)bytes});
-		}
+		if (!single_group || groups.empty()) build_packets();
 		for (void *s : group_stage) g.pool.put(s);
 		{
 			std::lock_guard<std::mutex> lk(g.mu);
