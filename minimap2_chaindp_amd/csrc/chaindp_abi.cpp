@@ -134,6 +134,10 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_sumq, nr * 8);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_units, (na / 2 + 1) * sizeof(Unit));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 2 * sizeof(unsigned long long));
+	size_t flags_bytes0 = 0, cblocks_bytes0 = 0;
+	chaindp::compact_scratch_bytes(ctx->cap_anchors, &flags_bytes0, &cblocks_bytes0);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_first_child, na * 4);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->cmp.flags, flags_bytes0);
 	size_t mask_bytes = 0, blocks_bytes = 0;
 	chaindp::prepass_scratch_bytes(ctx->cap_anchors, &mask_bytes, &blocks_bytes);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.start_mask, mask_bytes);
@@ -189,7 +193,8 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		es.n = 3;
 	}
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[0], st));
-	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, d_f, d_p, d_v, ctx->d_tg));
+	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, d_f, d_p, d_v, ctx->d_tg,
+	                                     ctx->d_first_child, ctx->cmp.flags));
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[1], st));
 	// per-read gap-cost table for the fast variant (skipped when the table would not apply)
 	uint16_t *lut = nullptr;
@@ -208,7 +213,7 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		HIP_TRY(ctx, chaindp::launch_lut(st, q, n_reads, d_off, ctx->d_sumq, lut_stride, lut));
 	}
 	HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, total / 2, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_units,
-	                                   ctx->d_counters, d_f, d_p, d_v, ctx->d_tg));
+	                                   ctx->d_counters, d_f, d_p, d_v, ctx->d_tg, ctx->d_first_child, ctx->cmp.flags));
 	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[2], st)); ctx->pending.push_back(es); }
 	ctx->stats[2] = total; ctx->stats[3] = n_reads;
 	return CHAINDP_OK;
@@ -299,13 +304,11 @@ static int compact_launch(chaindp_ctx *ctx, const chaindp_params_t *par)
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	if (!ctx->d_seeds) {
 		const size_t na = (size_t)ctx->cap_anchors, nr = (size_t)ctx->cap_reads;
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_first_child, na * 4));
 		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_id, na * 4));
 		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_seeds_off, (nr + 1) * 8));
 		HIP_TRY(ctx, hipMalloc(&ctx->d_seeds, na * sizeof(chaindp_seed_t)));
 		size_t flags_bytes = 0, blocks_bytes = 0;
 		chaindp::compact_scratch_bytes(ctx->cap_anchors, &flags_bytes, &blocks_bytes);
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->cmp.flags, flags_bytes));
 		HIP_TRY(ctx, hipMalloc((void**)&ctx->cmp.block_cnt, blocks_bytes));
 		HIP_TRY(ctx, hipMalloc((void**)&ctx->cmp.tile_tmp, blocks_bytes));
 		HIP_TRY(ctx, hipMalloc((void**)&ctx->cmp.n_seeds, 8));

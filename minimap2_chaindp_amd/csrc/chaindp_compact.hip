@@ -4,7 +4,7 @@
 // The reference compacts while it runs the recurrence, in anchor order:
 //   at step k: if p[k] >= 0 and p[k] has not been emitted yet, emit p[k] first ("late" emission,
 //   chain.c:287-303); then emit k itself iff v[k] >= min_sc || p[k] >= 0 (chain.c:304-316).
-// An anchor i is emitted at its own step iff self(i) = v[i] >= min_sc || p[i] >= 0; otherwise it is
+// An anchor i is emitted at its own step iff self(i) = v[i] >= min_sc || p[i] >= 0 (flags bit1); otherwise it is
 // emitted late, just before the FIRST later k with p[k] == i (if any).  Hence, per read:
 //   first_child[i] = min{k : p[k] == i}                      (only needed where !self(i))
 //   late(k)  = p[k] >= 0 && !self(p[k]) && first_child[p[k]] == k
@@ -115,27 +115,13 @@ hipError_t launch_scan_u64(hipStream_t st, int64_t n, unsigned long long *d_data
 
 #define NO_CHILD 0x7f7f7f7f   // hipMemsetAsync(0x7f) pattern; larger than any read-relative index in use
 
-// C1: first_child via atomicMin (only non-self predecessors, i.e. chain starts below min_sc, take atomics)
-__global__ __launch_bounds__(CMP_BLOCK) void k_first_child(Params par, int64_t n_reads, int64_t total,
-                                                           const int64_t *__restrict__ off, const int32_t *__restrict__ p,
-                                                           const int32_t *__restrict__ v, int32_t *__restrict__ first_child)
-{
-	const int64_t g0 = (int64_t)blockIdx.x * CMP_PER_BLOCK;
-	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
-	int64_t rlo, rhi;
-	block_read_range(off, n_reads, g0, g1, rlo, rhi);
-	for (int64_t g = g0 + threadIdx.x; g < g1; g += CMP_BLOCK) {
-		const int32_t q = p[g];
-		if (q < 0) continue;
-		const int64_t rs = off[rlo == rhi ? rlo : read_of_c(off, rlo, rhi, g)];
-		if (!self_emit(v[rs + q], p[rs + q], par.min_sc)) atomicMin(&first_child[rs + q], (int32_t)(g - rs));
-	}
-}
-
-// C2: per-anchor emission flags (bit0 late, bit1 self) and per-block record counts
-__global__ __launch_bounds__(CMP_BLOCK) void k_count(Params par, int64_t n_reads, int64_t total,
+// C1 happens inside the DP kernel's tile flush (k_chain_units) and the prepass (singletons): they set bit1 of
+// flags[] ("emitted at its own step") and feed first_child[] with atomicMin for predecessors that are not.
+// C2: late bit and per-block record counts.  first_child[q] == k can only hold for a q that is not emitted at
+// its own step, so no further look at v[q]/p[q] is needed.
+__global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t total,
                                                      const int64_t *__restrict__ off, const int32_t *__restrict__ p,
-                                                     const int32_t *__restrict__ v, const int32_t *__restrict__ first_child,
+                                                     const int32_t *__restrict__ first_child,
                                                      uint8_t *__restrict__ flags, unsigned long long *__restrict__ block_cnt)
 {
 	__shared__ unsigned int s_cnt;
@@ -147,14 +133,14 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_count(Params par, int64_t n_reads
 	unsigned int mine = 0;
 	for (int64_t g = g0 + threadIdx.x; g < g1; g += CMP_BLOCK) {
 		const int32_t q = p[g];
-		const bool self = self_emit(v[g], q, par.min_sc);
-		bool late = false;
+		const int self = (flags[g] >> 1) & 1;
+		int late = 0;
 		if (q >= 0) {
 			const int64_t rs = off[rlo == rhi ? rlo : read_of_c(off, rlo, rhi, g)];
-			late = !self_emit(v[rs + q], p[rs + q], par.min_sc) && first_child[rs + q] == (int32_t)(g - rs);
+			late = first_child[rs + q] == (int32_t)(g - rs);
+			if (late) flags[g] = (uint8_t)3;                    // q >= 0 implies self
 		}
-		flags[g] = (uint8_t)((int)late | ((int)self << 1));
-		mine += (unsigned int)late + (unsigned int)self;
+		mine += (unsigned int)(late + self);
 	}
 	for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d, 64);
 	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
@@ -264,11 +250,9 @@ hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, in
 	hipError_t e;
 	if (n_reads <= 0) return hipMemsetAsync(d_seeds_off, 0, sizeof(int64_t), st);
 	if (total <= 0) return hipMemsetAsync(d_seeds_off, 0, (size_t)(n_reads + 1) * sizeof(int64_t), st);
-	if ((e = hipMemsetAsync(d_first_child, 0x7f, (size_t)total * 4, st)) != hipSuccess) return e;
 	const int64_t blocks = (total + CMP_PER_BLOCK - 1) / CMP_PER_BLOCK;
 	const dim3 g((unsigned)blocks), b(CMP_BLOCK);
-	hipLaunchKernelGGL(k_first_child, g, b, 0, st, par, n_reads, total, d_off, d_p, d_v, d_first_child);
-	hipLaunchKernelGGL(k_count, g, b, 0, st, par, n_reads, total, d_off, d_p, d_v, d_first_child, sc.flags, sc.block_cnt);
+	hipLaunchKernelGGL(k_count, g, b, 0, st, n_reads, total, d_off, d_p, d_first_child, sc.flags, sc.block_cnt);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, sc.n_seeds)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_positions, g, b, 0, st, n_reads, total, d_off, d_p, sc.flags, sc.block_cnt, d_id, d_seeds_off);
 	hipLaunchKernelGGL(k_finish_offsets, dim3(1), dim3(1), 0, st, n_reads, total, d_off, sc.n_seeds, d_seeds_off);

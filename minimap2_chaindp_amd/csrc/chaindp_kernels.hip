@@ -142,7 +142,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_rea
                                                        unsigned long long *__restrict__ sumq, uint64_t *__restrict__ start_mask,
                                                        unsigned long long *__restrict__ block_cnt,
                                                        int32_t *__restrict__ f, int32_t *__restrict__ p, int32_t *__restrict__ v,
-                                                       int32_t *__restrict__ tg)
+                                                       int32_t *__restrict__ tg, uint8_t *__restrict__ flags)
 {
 	__shared__ int64_t s_rlo, s_rhi;
 	__shared__ unsigned int s_sum, s_units, s_singles;
@@ -175,7 +175,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_rea
 			const bool next_starts = g + 1 >= re || a[g + 1].x - an.x > maxx;
 			single = start && next_starts;
 			tg[g] = 0;
-			if (single) { f[g] = span; p[g] = -1; v[g] = span; }   // chain.c:251,283-284 with an empty window
+			if (single) {                                          // chain.c:251,283-284 with an empty window
+				f[g] = span; p[g] = -1; v[g] = span;
+				flags[g] = (uint8_t)(span >= par.min_sc ? 2 : 0);  // emitted at its own step iff v >= min_sc (chain.c:304)
+			}
 		}
 		// q_span sum (chain.c:240): per block when the block sits inside one read, else per wave when the
 		// wave does, else (the one wave that straddles a read boundary) per lane
@@ -280,6 +283,9 @@ __device__ __forceinline__ uint32_t absdiff_u32(uint32_t x, uint32_t y)
 struct UnitCtx {
 	const ulonglong2 *a;
 	int32_t *f, *p, *v, *tg;
+	int32_t *first_child;   // compaction helper, see chaindp_compact.hip
+	uint8_t *flags;
+	int min_sc;
 	uint32_t *s_w;          // ring entries, 4 dwords each
 	int *s_t, *s_v;
 	uint32_t *s_xhi, *s_yhi;
@@ -538,9 +544,20 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 		if (lane < cnt) {
 			const int my_slot = (tile0 + lane) & MASK;
 			const int2 fp = *(const int2*)(c.s_w + 4 * my_slot + 2);
+			const int vi = c.s_v[my_slot];
 			c.f[gi] = fp.x;
 			c.p[gi] = fp.y < 0 ? -1 : fp.y + c.rel0;
-			c.v[gi] = c.s_v[my_slot];
+			c.v[gi] = vi;
+			// Compaction (chain.c:286-317) needs, for every anchor that is not emitted at its own step, its
+			// first child; while f/p/v of the tile are at hand, record "emitted at own step" and feed that min.
+			const int q = fp.y;
+			if (q >= 0) {
+				int vq, pq;
+				if (tile0 + cnt - 1 - q < RING) { vq = c.s_v[q & MASK]; pq = (int)c.s_w[4 * (q & MASK) + 3]; }
+				else { vq = c.v[c.base + q]; pq = c.p[c.base + q]; }
+				if (!(vq >= c.min_sc || pq >= 0)) atomicMin(&c.first_child[c.base + q], c.rel0 + tile0 + lane);
+			}
+			c.flags[gi] = (uint8_t)((vi >= c.min_sc || q >= 0) ? 2 : 0);
 		}
 		if (cnt < 64) break;
 	}
@@ -553,12 +570,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                     const uint16_t *__restrict__ lut, int lut_stride,
                                                     const Unit *__restrict__ units,
                                                     const unsigned long long *__restrict__ counters,
-                                                    int32_t *f, int32_t *p, int32_t *v, int32_t *tg)
+                                                    int32_t *f, int32_t *p, int32_t *v, int32_t *tg,
+                                                    int32_t *first_child, uint8_t *flags)
 {
 	static_assert((RING & (RING - 1)) == 0 && RING >= 128, "RING must be a power of two >= 128");
 	extern __shared__ uint4 smem[];
 	UnitCtx c;
-	c.a = a; c.f = f; c.p = p; c.v = v; c.tg = tg;
+	c.a = a; c.f = f; c.p = p; c.v = v; c.tg = tg; c.first_child = first_child; c.flags = flags; c.min_sc = par.min_sc;
 	c.s_w = (uint32_t*)smem;
 	c.s_t = (int*)(c.s_w + 4 * RING);
 	c.s_v = c.s_t + RING;
@@ -606,15 +624,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
 hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off, const void *d_a,
                           unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
-                          int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg)
+                          int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg, int32_t *d_first_child, uint8_t *d_flags)
 {
 	hipError_t e = hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st);
 	if (e != hipSuccess || n_reads <= 0 || total <= 0) return e;
 	if ((e = hipMemsetAsync(d_sumq, 0, (size_t)n_reads * sizeof(unsigned long long), st)) != hipSuccess) return e;
+	if ((e = hipMemsetAsync(d_first_child, 0x7f, (size_t)total * 4, st)) != hipSuccess) return e;   // "no child" (chaindp_compact.hip)
 	const int64_t blocks = (total + PRE_PER_BLOCK - 1) / PRE_PER_BLOCK;
 	const int64_t words = (total + 63) / 64;
 	hipLaunchKernelGGL(k_prepass, dim3((unsigned)blocks), dim3(PRE_BLOCK), 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a,
-	                   d_sumq, sc.start_mask, sc.block_cnt, d_f, d_p, d_v, d_tg);
+	                   d_sumq, sc.start_mask, sc.block_cnt, d_f, d_p, d_v, d_tg, d_flags);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, d_counters)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_emit_units, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, n_reads, words, d_off,
 	                   sc.start_mask, sc.block_cnt, d_units);
@@ -646,7 +665,7 @@ hipError_t launch_lut(hipStream_t st, const Params &par, int64_t n_reads, const 
 hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
                         const int32_t *d_n_segs, const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
                         const Unit *d_units, const unsigned long long *d_counters,
-                        int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg)
+                        int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg, int32_t *d_first_child, uint8_t *d_flags)
 {
 	if (max_units <= 0) return hipSuccess;
 	// The number of units is only known on the device (counters[0]); the grid is sized for the upper
@@ -657,9 +676,9 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
 	const ulonglong2 *aa = (const ulonglong2*)d_a;
 	const size_t lds = chain_lds_bytes(ring, d_lut ? lut_stride : 0);
 	switch (ring) {
-	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
-	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
-	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg); break;
+	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, d_first_child, d_flags); break;
+	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, d_first_child, d_flags); break;
+	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, d_first_child, d_flags); break;
 	}
 	return hipGetLastError();
 }
