@@ -76,7 +76,7 @@ struct Result { void *buf; int size; };
 
 struct Service {
 	bool up = false;
-	int n_gpus_cfg = 0, max_packets = 64;
+	int n_gpus_cfg = 0, max_packets = 64, services_per_gpu = 2;
 	unsigned long max_inflight = 1ul << 30;
 	// fpga_set_params (main.c:243)
 	int bw = 500, is_cdna = 0, max_skip = 25, min_sc = 40, flag = 0, max_occ = 0;
@@ -111,7 +111,7 @@ void fail_hard(const char *what)
 
 void service_loop(int device)
 {
-	const int64_t cap_anchors = 64ll << 20, cap_reads = 1 << 20;   // 1 GiB of anchors per batch at most
+	const int64_t cap_anchors = 32ll << 20, cap_reads = 1 << 19;   // 512 MiB of anchors per batch at most
 	chaindp_ctx_t *ctx = chaindp_create(device, cap_anchors, cap_reads);
 	if (!ctx) { fprintf(stderr, "[chaindp-fpga] %s\n", chaindp_last_error(nullptr)); fail_hard("cannot create a device context"); }
 	std::vector<Submitted> pk;
@@ -289,7 +289,9 @@ extern "C" int fpga_init(int flag)
 	if (g.n_gpus_cfg > 0 && g.n_gpus_cfg < n) n = g.n_gpus_cfg;
 	g.stopping = false; g.exit_block = false;
 	for (int k = 0; k < 5; ++k) g.stats[k] = 0;
-	for (int d = 0; d < n; ++d) g.workers.emplace_back(service_loop, d);
+	// two service threads (two contexts, two streams) per GPU: while one batch is in its kernels the other one's
+	// packets cross PCIe, in either direction
+	for (int d = 0; d < n; ++d) for (int k = 0; k < g.services_per_gpu; ++k) g.workers.emplace_back(service_loop, d);
 	g.up = true;
 	return 0;
 }
