@@ -141,7 +141,7 @@ def main():
             "roofline": {
                 "kernel": "k_chain_units", "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(total),
                 "algorithmic_bytes_per_anchor": ALGO_BYTES_PER_ANCHOR, "anchors_per_launch": total,
                 "avg_launch_ms": dp_ms,
             },
@@ -155,6 +155,21 @@ def main():
     dev.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(anchors_per_launch):
+    """HBM bytes per launch of the DP kernel from the PMC passes of tools/profile.sh on this same workload
+    (profiles/latest_traffic.json; FETCH_SIZE/WRITE_SIZE collected and corrected as MI355X_MICROARCH.md
+    prescribes).  PMC collection cannot run inside the timed process, so this is null unless a profile of the
+    same batch size is committed."""
+    path = os.path.join(ROOT, "profiles", "latest_traffic.json")
+    try:
+        t = json.load(open(path))
+        if t.get("anchors_per_launch") == anchors_per_launch:
+            return t["hbm_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        pass
+    return None
 
 
 def cpu_baseline(par, off, anchors, sample_anchors, threads):

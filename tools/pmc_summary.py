@@ -47,5 +47,10 @@ if ck and anchors:
         rd, wr = 2 * c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
         print(f"    HBM traffic per launch: read {rd/1e6:.1f} MB (FETCH_SIZE x2 gfx950 correction), write {wr/1e6:.1f} MB,"
               f" total {(rd+wr)/anchors:.1f} B/anchor (algorithmic 24 B/anchor)")
+        with open(os.path.join(d, "traffic.json"), "w") as fh:
+            json.dump({"kernel": ck, "anchors_per_launch": anchors, "hbm_read_bytes": rd, "hbm_write_bytes": wr,
+                       "hbm_bytes_per_launch": rd + wr,
+                       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KiB -> bytes, "
+                                 "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B), average over launches"}, fh)
     if "GRBM_GUI_ACTIVE" in c:
         print(f"    GRBM_GUI_ACTIVE/8 = {c['GRBM_GUI_ACTIVE']/8/1e6:.2f} M cycles")
