@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--preset", default="ava-ont", help="generator + DP preset (ava-ont, map-ont, skew)")
     ap.add_argument("--ring", type=int, default=0, help="LDS ring capacity override (128/256/512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (end-to-end rate, copy bandwidth, pair evaluations)")
     ap.add_argument("--cpu-sample-anchors", type=int, default=40_000_000)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the CPU baseline (16 = one GPU's share of the box)")
     ap.add_argument("--host-threads", type=int, default=16, help="host threads of the synthetic generator")
@@ -110,6 +111,10 @@ def main():
     if world > 1:
         dist.barrier()
 
+    extras = {}
+    if rank == 0 and not args.no_extras:
+        extras = measure_extras(torch, dev, par, off, anchors, total)
+
     if rank == 0:
         steps = max(args.steps, 1)
         value = total_all * steps / elapsed_max
@@ -148,6 +153,11 @@ def main():
             "kernel_ms": {"prepass": pre_ms, "chain_dp": dp_ms, "compact": cmp_ms},
             "host": {"generate_s": t_gen, "upload_s": t_up, "upload_GBps": total * 16 / t_up / 1e9 if t_up > 0 else None},
         }
+        out.update(extras)
+        if "pair_evals_per_anchor" in extras:
+            out["pair_evals_per_s"] = value * extras["pair_evals_per_anchor"]
+        if "device_copy_GBps" in extras:
+            out["roofline"]["frac_of_measured_copy_bw"] = achieved / extras["device_copy_GBps"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(par, off, anchors, args.cpu_sample_anchors, args.cpu_threads)
         print(json.dumps(out), flush=True)
@@ -155,6 +165,42 @@ def main():
     dev.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def measure_extras(torch, dev, par, off, anchors, total):
+    """Side measurements BASELINE.md asks to report next to the headline (none of them is `value`):
+    the PCIe-inclusive end-to-end rate (host anchors in, f/p/v and new_seed[] back out, pageable host memory),
+    the device copy bandwidth (practical HBM ceiling), and pair evaluations (executions of chain.c:254)."""
+    ex = {}
+    t0 = time.perf_counter()
+    f, p, v = dev.chain_batch(par, off, anchors)
+    soff, seeds = dev.compact(par)
+    dt = time.perf_counter() - t0
+    ex["end_to_end"] = {"anchors_per_s": total / dt, "seconds": dt,
+                        "includes": "H2D of anchors, prepass + chain DP + compaction, D2H of f/p/v and new_seed[] (pageable host buffers)"}
+    n = 1 << 28                                                  # 1 GiB of int32 each way
+    src = torch.empty(n, dtype=torch.int32, device="cuda")
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    ex["device_copy_GBps"] = 5 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9      # read + write bytes
+    del src, dst
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as ol
+        k = min(200, len(off) - 1)
+        so = np.ascontiguousarray(off[:k + 1])
+        _, _, _, evals = ol.oracle_batch(par, so, np.ascontiguousarray(anchors[:int(so[-1])]), threads=8)
+        ex["pair_evals_per_anchor"] = evals / max(int(so[-1]), 1)     # inner-loop executions of the scalar algorithm
+    except Exception:  # noqa: BLE001
+        pass
+    return ex
 
 
 def measured_traffic(anchors_per_launch):

@@ -615,8 +615,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 			for (int k = lane; k < RING; k += 64) *(uint4*)(c.s_w + 4 * k) = make_uint4(x_none, 0u, 0u, 0xffffffffu);
 		}
 		wave_mem_fence();
-		if (general) run_unit<RING, true>(c, re - u.start);
-		else run_unit<RING, false>(c, re - u.start);
+		// units are emitted in anchor order, so the next unit's start bounds this one (tile prefetch stops there)
+		int64_t lim = re;
+		if (ub + 1 < n_units) { const int64_t nxt = units[ub + 1].start; lim = nxt < re && nxt > u.start ? nxt : re; }
+		if (general) run_unit<RING, true>(c, lim - u.start);
+		else run_unit<RING, false>(c, lim - u.start);
 	}
 }
 
