@@ -70,7 +70,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     gen_preset = args.preset
-    dp_preset = "ava-ont" if args.preset == "skew" else args.preset
+    dp_preset = args.preset if args.preset in params.PRESETS else "ava-ont"      # skew / dense / ties use ava-ont gaps
     par = params.preset(dp_preset)
 
     # ---- this rank's shard of the job, generated on the host, then made resident in HBM

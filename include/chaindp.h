@@ -89,6 +89,18 @@ int chaindp_compact(chaindp_ctx_t *ctx, const chaindp_params_t *par, int64_t *se
  * for a resident batch.  This is what bench.py times. */
 int chaindp_run_full(chaindp_ctx_t *ctx, const chaindp_params_t *par);
 
+/* The HOST half of the reference's split as well, on the GPU: mm_chain_dp_bottom
+ * (chain.c:329-431) for every read of the resident batch, from the compaction's new_seed[] (call after
+ * chaindp_compact / chaindp_compact_offsets / chaindp_run_full).  min_sc comes from par, min_cnt is the
+ * reference's first argument.  Outputs, per read r and in the reference's order (chains sorted by the x of their
+ * first anchor, ties as its radix sort leaves them):
+ *   chains_off[n_reads+1]   CSR offsets of the kept chains;  u[] = score<<32 | anchor count (the reference's u[])
+ *   b_off[n_reads+1]        CSR offsets of the chained anchors;  b[] = the chains' anchors, one chain after the other
+ * u needs room for chains_off[n_reads] entries and b for b_off[n_reads]; both are bounded by the batch's record
+ * count (seeds_off[n_reads]).  Pass u = b = NULL to get only the offsets. */
+int chaindp_backtrack(chaindp_ctx_t *ctx, const chaindp_params_t *par, int min_cnt,
+                      int64_t *chains_off, uint64_t *u, int64_t *b_off, chaindp_anchor_t *b);
+
 /* Scatter/gather variants used by the packet shim, whose reads sit in separate (pinned) packet
  * buffers: upload from one host pointer per read; run the compaction and return only the offsets;
  * then copy each read's new_seed[] straight to its place in a result packet (asynchronous on the

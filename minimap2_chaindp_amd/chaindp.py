@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     "chaindp_upload", "chaindp_run", "chaindp_sync", "chaindp_download", "chaindp_compact",
     "chaindp_upload_gather", "chaindp_compact_offsets", "chaindp_download_seeds", "chaindp_host_alloc",
     "chaindp_host_free", "chaindp_run_device", "chaindp_set_profiling", "chaindp_get_kernel_ms",
-    "chaindp_get_stats", "chaindp_set_ring", "chaindp_run_full", "chaindp_set_variant", "chaindp_upload_gather_ex", "chaindp_scatter_seeds",
+    "chaindp_get_stats", "chaindp_set_ring", "chaindp_run_full", "chaindp_set_variant", "chaindp_upload_gather_ex", "chaindp_scatter_seeds", "chaindp_backtrack",
 )
 
 
@@ -67,6 +67,7 @@ def lib():
         L.chaindp_get_stats.argtypes = [vp, vp]
         L.chaindp_set_ring.argtypes = [vp, i32]
         L.chaindp_set_variant.argtypes = [vp, i32]
+        L.chaindp_backtrack.argtypes = [vp, P, i32, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -167,6 +168,17 @@ class Device:
         seeds = np.zeros(max(self._total, 1), SEED_DTYPE)
         self._check(self._lib.chaindp_compact(self._ctx, C.byref(par), _ptr(soff), _ptr(seeds)))
         return soff, seeds[:int(soff[-1])]
+
+    def backtrack(self, par, min_cnt=3):
+        """mm_chain_dp_bottom (chain.c:329-431) of every read on the GPU, after compact()/run_full():
+        (chains_off, u uint64[...], b_off, b uint64[...,2])."""
+        coff = np.zeros(self._n_reads + 1, np.int64)
+        boff = np.zeros(self._n_reads + 1, np.int64)
+        cap = max(self._total, 1)
+        u = np.zeros(cap, np.uint64)
+        b = np.zeros((cap, 2), np.uint64)
+        self._check(self._lib.chaindp_backtrack(self._ctx, C.byref(par), min_cnt, _ptr(coff), _ptr(u), _ptr(boff), _ptr(b)))
+        return coff, u[:int(coff[-1])], boff, b[:int(boff[-1])]
 
     # -- device-pointer path (torch tensors or any other HBM allocation)
     def run_device(self, par, n_reads, total, d_off, d_a, d_n_segs, d_f, d_p, d_v, stream=0):

@@ -37,6 +37,8 @@ struct chaindp_ctx {
 	unsigned long long *d_counters = nullptr;
 	chaindp::PrepassScratch pre = {nullptr, nullptr, nullptr};
 	chaindp::CompactScratch cmp = {nullptr, nullptr, nullptr, nullptr};
+	chaindp::BottomScratch bot = {};
+	std::vector<void*> bot_allocs;
 	uint16_t *d_lut = nullptr;
 	void **d_ptrs = nullptr;         // per-read host pointers for the gather / scatter kernels
 	size_t ptr_cap = 0;
@@ -105,6 +107,7 @@ extern "C" void chaindp_destroy(chaindp_ctx_t *ctx)
 	void *bufs[] = {ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_sumq, ctx->d_units,
 	                ctx->d_counters, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
 	for (void *b : bufs) if (b) hipFree(b);
+	for (void *b : ctx->bot_allocs) if (b) hipFree(b);
 	if (ctx->stream) hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -333,6 +336,87 @@ static int compact_on_device(chaindp_ctx *ctx, const chaindp_params_t *par, int6
 	HIP_TRY(ctx, hipMemcpyAsync(seeds_off, ctx->d_seeds_off, (size_t)(ctx->n_reads + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	ctx->n_seeds = seeds_off[ctx->n_reads];
+	return CHAINDP_OK;
+}
+
+template <typename T>
+static hipError_t bot_alloc(chaindp_ctx *ctx, T *&p, size_t bytes)
+{
+	void *q = nullptr;
+	hipError_t e = hipMalloc(&q, bytes ? bytes : 8);
+	if (e == hipSuccess) { ctx->bot_allocs.push_back(q); p = (T*)q; }
+	return e;
+}
+
+extern "C" int chaindp_backtrack(chaindp_ctx_t *ctx, const chaindp_params_t *par, int min_cnt,
+                                 int64_t *chains_off, uint64_t *u, int64_t *b_off, chaindp_anchor_t *b)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	int rc = check_params(ctx, par);
+	if (rc) return rc;
+	if (!ctx->ran || !ctx->d_seeds) { ctx->err = "chaindp_backtrack needs a completed run and compaction"; return CHAINDP_ERR_ARG; }
+	if (!chains_off || !b_off) { ctx->err = "NULL output"; return CHAINDP_ERR_ARG; }
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	// the record count of the last compaction (it may have been launched asynchronously by chaindp_run_full)
+	unsigned long long n_seeds = 0;
+	HIP_TRY(ctx, hipMemcpyAsync(&n_seeds, ctx->cmp.n_seeds, 8, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	const int64_t m = ctx->total > 0 && ctx->n_reads > 0 ? (int64_t)(uint32_t)n_seeds : 0;
+	ctx->n_seeds = m;
+	if (!ctx->bot.has) {
+		const size_t M = (size_t)ctx->cap_anchors, R = (size_t)ctx->cap_reads, NB = M / 1024 + 2;
+		chaindp::BottomScratch &s = ctx->bot;
+		HIP_TRY(ctx, bot_alloc(ctx, s.has, M));
+		HIP_TRY(ctx, bot_alloc(ctx, s.owner, M * 4)); HIP_TRY(ctx, bot_alloc(ctx, s.end_rec, M * 4)); HIP_TRY(ctx, bot_alloc(ctx, s.ccnt, M * 4));
+		HIP_TRY(ctx, bot_alloc(ctx, s.kpos, M * 4)); HIP_TRY(ctx, bot_alloc(ctx, s.bpos, M * 4));
+		HIP_TRY(ctx, bot_alloc(ctx, s.c_src, M * 4)); HIP_TRY(ctx, bot_alloc(ctx, s.c_dst, M * 4));
+		HIP_TRY(ctx, bot_alloc(ctx, s.key, M * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.skey, M * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.cu, M * 8));
+		HIP_TRY(ctx, bot_alloc(ctx, s.u_tmp, M * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.u_out, M * 8));
+		HIP_TRY(ctx, bot_alloc(ctx, s.b_tmp, M * 16)); HIP_TRY(ctx, bot_alloc(ctx, s.b_out, M * 16)); HIP_TRY(ctx, bot_alloc(ctx, s.w, M * 16));
+		HIP_TRY(ctx, bot_alloc(ctx, s.stacks, (M / 64 + 2 * R + 4) * 12));
+		HIP_TRY(ctx, bot_alloc(ctx, s.block_cnt, (NB > R + 2 ? NB : R + 2) * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.tile_tmp, (NB > R + 2 ? NB : R + 2) * 8));
+		HIP_TRY(ctx, bot_alloc(ctx, s.read_tot, (R + 2) * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.total, 8));
+		HIP_TRY(ctx, bot_alloc(ctx, s.ends_off, (R + 2) * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.chains_off, (R + 2) * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.b_off, (R + 2) * 8));
+	}
+	HIP_TRY(ctx, chaindp::launch_backtrack(ctx->stream, min_cnt, par->min_sc, ctx->n_reads, ctx->cap_anchors, ctx->d_seeds_off, ctx->d_seeds,
+	                                       ctx->cmp.n_seeds, ctx->bot, m));
+	const size_t ob = (size_t)(ctx->n_reads > 0 ? ctx->n_reads + 1 : 1) * 8;
+	HIP_TRY(ctx, hipMemcpyAsync(chains_off, ctx->bot.chains_off, ob, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(b_off, ctx->bot.b_off, ob, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	const int64_t n_c = ctx->n_reads > 0 ? chains_off[ctx->n_reads] : 0, n_b = ctx->n_reads > 0 ? b_off[ctx->n_reads] : 0;
+	if (u && n_c > 0) HIP_TRY(ctx, hipMemcpyAsync(u, ctx->bot.u_out, (size_t)n_c * 8, hipMemcpyDeviceToHost, ctx->stream));
+	if (b && n_b > 0) HIP_TRY(ctx, hipMemcpyAsync(b, ctx->bot.b_out, (size_t)n_b * 16, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return CHAINDP_OK;
+}
+
+// test hook (not in the public header): fills one of the backtrack allocations (in allocation order) with a byte
+extern "C" int chaindp_debug_poison(chaindp_ctx_t *ctx, int which, int byte, size_t bytes)
+{
+	if (!ctx || which < 0 || (size_t)which >= ctx->bot_allocs.size()) return CHAINDP_ERR_ARG;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipMemset(ctx->bot_allocs[which], byte, bytes));
+	return CHAINDP_OK;
+}
+
+// test hook (not in the public header): copies one of the backtrack scratch arrays to the host
+extern "C" int chaindp_debug_bottom(chaindp_ctx_t *ctx, int which, void *dst, size_t bytes)
+{
+	if (!ctx || !ctx->bot.has) return CHAINDP_ERR_ARG;
+	const void *src = nullptr;
+	switch (which) {
+	case 0: src = ctx->bot.has; break;
+	case 1: src = ctx->bot.owner; break;
+	case 2: src = ctx->bot.skey; break;
+	case 3: src = ctx->bot.ccnt; break;
+	case 4: src = ctx->bot.key; break;
+	case 5: src = ctx->bot.end_rec; break;
+	case 6: src = ctx->bot.ends_off; break;
+	default: return CHAINDP_ERR_ARG;
+	}
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
 	return CHAINDP_OK;
 }
 

@@ -1,0 +1,414 @@
+// chaindp_bottom.hip -- the host half of the reference's chaining split, mm_chain_dp_bottom
+// (reference chain.c:329-431), for every read of a resident batch, as GPU kernels.
+//
+// Input: the batch's new_seed[] records (compaction output) with their per-read offsets.  Per read the
+// reference does, sequentially:
+//   1. chain ends = records with the "v >= min_sc" flag that nobody points at          (chain.c:346-354)
+//   2. per end, walk to the peak of f along the "f < v" flags; key = f[peak]<<32 | peak   (chain.c:362-370)
+//   3. sort the keys, best first                                                          (chain.c:371-375)
+//   4. in that order, backtrack each chain until an already visited record; keep it if long enough and, when
+//      it ran into an older chain, if it still gained min_sc                              (chain.c:378-393)
+//   5. emit the kept chains' anchors (ascending), then re-order the chains by the x of their first anchor
+//      with the reference's unstable radix sort                                           (chain.c:401-426)
+// Step 4 is the only order-dependent part.  A record is "visited" by the best-ranked chain whose full path to
+// the root contains it (a chain stops at the first record a better chain reached, and that better chain, or a
+// still better one, continues along the same path), so with owner[x] = min rank over the chains whose path
+// contains x, chain k consists of its peak (always taken: chain.c:381 is a do-while) and the records below it while
+// owner == k, and it stopped at the first record with owner < k.  owner[] is built with atomicMin by one walker per chain that stops as soon as it
+// meets a smaller rank (whoever owns that record keeps walking).  Discarded chains still own their records,
+// exactly as the reference leaves its t[] marks set (chain.c:392).
+// Step 5's sort is unstable; its output order for equal keys is reproduced by running the reference's exact
+// procedure (ksort.h:101-151) sequentially, one thread per read -- reads have tens of chains.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "chaindp_kernels.h"
+
+namespace chaindp {
+
+struct SeedRec { uint64_t x, y; int32_t p, f; };   // == struct new_seed (minimap.h:51-55)
+
+#define BT_BLOCK 256
+#define BT_PER_BLOCK 1024
+
+// largest r in [lo, hi] with off[r] <= g
+__device__ __forceinline__ int64_t bt_read_of(const int64_t *__restrict__ off, int64_t lo, int64_t hi, int64_t g)
+{
+	while (lo < hi) {
+		const int64_t mid = (lo + hi + 1) >> 1;
+		if (off[mid] <= g) lo = mid; else hi = mid - 1;
+	}
+	return lo;
+}
+
+// B1: has[j] = 1 if some record of the same read points at j (chain.c:347-349)
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_children(int64_t n_reads, int64_t m, const int64_t *__restrict__ soff,
+                                                          const SeedRec *__restrict__ s, uint8_t *__restrict__ has)
+{
+	for (int64_t g = (int64_t)blockIdx.x * BT_BLOCK + threadIdx.x; g < m; g += (int64_t)gridDim.x * BT_BLOCK) {
+		const int32_t p = s[g].p;
+		if (p >= 0) has[soff[bt_read_of(soff, 0, n_reads - 1, g)] + (p >> 2)] = 1;
+	}
+}
+
+// B2: chain ends per 1024-record block (chain.c:350-354)
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_end_count(int64_t m, const SeedRec *__restrict__ s, const uint8_t *__restrict__ has,
+                                                           unsigned long long *__restrict__ block_cnt)
+{
+	__shared__ unsigned int s_cnt;
+	if (threadIdx.x == 0) s_cnt = 0;
+	__syncthreads();
+	const int64_t g0 = (int64_t)blockIdx.x * BT_PER_BLOCK;
+	const int64_t g1 = g0 + BT_PER_BLOCK < m ? g0 + BT_PER_BLOCK : m;
+	unsigned int mine = 0;
+	for (int64_t g = g0 + threadIdx.x; g < g1; g += BT_BLOCK) mine += (unsigned int)((s[g].p & 1) && !has[g]);
+	for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d, 64);
+	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
+	__syncthreads();
+	if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_cnt;
+}
+
+// B3: the ends, in record order, as a flat list with per-read offsets (ends_off[r] = list position at the read's
+// first record; reads without records share their successor's value, the tail is closed by k_bt_close_offsets)
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_end_list(int64_t n_reads, int64_t m, const int64_t *__restrict__ soff,
+                                                          const SeedRec *__restrict__ s, const uint8_t *__restrict__ has,
+                                                          const unsigned long long *__restrict__ block_base,
+                                                          int32_t *__restrict__ end_rec, int64_t *__restrict__ ends_off)
+{
+	__shared__ unsigned int s_w[4];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int64_t g0 = (int64_t)blockIdx.x * BT_PER_BLOCK;
+	const int64_t g1 = g0 + BT_PER_BLOCK < m ? g0 + BT_PER_BLOCK : m;
+	unsigned int carry = (unsigned int)block_base[blockIdx.x];
+	for (int64_t gb = g0; gb < g1; gb += BT_BLOCK) {
+		const int64_t g = gb + threadIdx.x;
+		const bool is_end = g < g1 && (s[g].p & 1) && !has[g];
+		const uint64_t bm = __builtin_amdgcn_ballot_w64(is_end);
+		const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+		if (lane == 0) s_w[wave] = __builtin_popcountll(bm);
+		__syncthreads();
+		unsigned int woff = 0, tot = 0;
+		for (int w = 0; w < 4; ++w) { const unsigned int t = s_w[w]; if (w < wave) woff += t; tot += t; }
+		const unsigned int pos = carry + woff + __builtin_popcountll(bm & below);
+		if (g < g1) {
+			const int64_t r = bt_read_of(soff, 0, n_reads - 1, g);
+			const int64_t so = soff[r];
+			if (is_end) end_rec[pos] = (int32_t)(g - so);
+			if (g == so) for (int64_t rr = r; rr >= 0 && soff[rr] == so; --rr) ends_off[rr] = (int64_t)pos;
+		}
+		carry += tot;
+		__syncthreads();
+	}
+}
+
+__global__ void k_bt_close_offsets(int64_t n_reads, int64_t m, const int64_t *__restrict__ soff,
+                                   const unsigned long long *__restrict__ total, int64_t *__restrict__ offs)
+{
+	const int64_t t = (int64_t)(uint32_t)*total;
+	offs[n_reads] = t;
+	for (int64_t r = n_reads - 1; r >= 0 && soff[r] == m; --r) offs[r] = t;
+}
+
+// B4: walk every end to the peak of f (chain.c:362-370)
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_peaks(int64_t n_reads, const int64_t *__restrict__ soff, const SeedRec *__restrict__ s,
+                                                       const int64_t *__restrict__ ends_off, const int32_t *__restrict__ end_rec,
+                                                       unsigned long long *__restrict__ key)
+{
+	const int64_t n_e = ends_off[n_reads];
+	for (int64_t e = (int64_t)blockIdx.x * BT_BLOCK + threadIdx.x; e < n_e; e += (int64_t)gridDim.x * BT_BLOCK) {
+		const SeedRec *sr = s + soff[bt_read_of(ends_off, 0, n_reads - 1, e)];
+		const int32_t i = end_rec[e];
+		int32_t j = i;
+		while (j >= 0 && (sr[j].p & 2)) j = sr[j].p >> 2;
+		if (j < 0) j = i;
+		key[e] = (unsigned long long)(long long)sr[j].f << 32 | (unsigned long long)(uint32_t)j;
+	}
+}
+
+// B5: per read, keys in descending order (chain.c:371-375), by counting.  Two ends can share a peak and then have
+// identical keys; equal keys are interchangeable (whichever comes second finds its peak visited), so ties are
+// simply broken by list position.
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_rank(int64_t n_reads, const int64_t *__restrict__ ends_off,
+                                                      const unsigned long long *__restrict__ key, unsigned long long *__restrict__ skey)
+{
+	__shared__ unsigned long long tile[1024];
+	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+		const int64_t b = ends_off[r], n = ends_off[r + 1] - b;
+		if (n <= 0) continue;
+		for (int64_t e0 = 0; e0 < n; e0 += BT_BLOCK) {              // every thread ranks one key per round
+			const int64_t e = e0 + threadIdx.x;
+			const unsigned long long mine = e < n ? key[b + e] : 0;
+			int64_t rank = 0;
+			for (int64_t t0 = 0; t0 < n; t0 += 1024) {
+				__syncthreads();
+				for (int k = threadIdx.x; k < 1024; k += BT_BLOCK) tile[k] = t0 + k < n ? key[b + t0 + k] : 0;
+				__syncthreads();
+				const int lim = n - t0 < 1024 ? (int)(n - t0) : 1024;
+				for (int k = 0; k < lim; ++k) rank += tile[k] > mine || (tile[k] == mine && t0 + k < e);
+			}
+			if (e < n) skey[b + rank] = mine;
+		}
+		__syncthreads();
+	}
+}
+
+// B6: owner[x] = best (smallest) rank among the chains whose path contains x
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_own(int64_t n_reads, const int64_t *__restrict__ soff, const SeedRec *__restrict__ s,
+                                                     const int64_t *__restrict__ ends_off, const unsigned long long *__restrict__ skey,
+                                                     int32_t *__restrict__ owner)
+{
+	const int64_t n_e = ends_off[n_reads];
+	for (int64_t c = (int64_t)blockIdx.x * BT_BLOCK + threadIdx.x; c < n_e; c += (int64_t)gridDim.x * BT_BLOCK) {
+		const int64_t r = bt_read_of(ends_off, 0, n_reads - 1, c);
+		const int32_t k = (int32_t)(c - ends_off[r]);
+		const SeedRec *sr = s + soff[r];
+		int32_t *ow = owner + soff[r];
+		int32_t j = (int32_t)(uint32_t)skey[c];
+		while (j >= 0) {
+			if (atomicMin(&ow[j], k) < k) break;                    // a better chain owns it and walks on from here
+			const int32_t p = sr[j].p;
+			j = p >= 0 ? p >> 2 : -1;
+		}
+	}
+}
+
+// B7: length, score and fate of every chain (chain.c:380-392)
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_score(int64_t n_reads, int min_cnt, int min_sc, const int64_t *__restrict__ soff,
+                                                       const SeedRec *__restrict__ s, const int64_t *__restrict__ ends_off,
+                                                       const unsigned long long *__restrict__ skey, const int32_t *__restrict__ owner,
+                                                       int32_t *__restrict__ ccnt, unsigned long long *__restrict__ cu)
+{
+	const int64_t n_e = ends_off[n_reads];
+	for (int64_t c = (int64_t)blockIdx.x * BT_BLOCK + threadIdx.x; c < n_e; c += (int64_t)gridDim.x * BT_BLOCK) {
+		const int64_t r = bt_read_of(ends_off, 0, n_reads - 1, c);
+		const int32_t k = (int32_t)(c - ends_off[r]);
+		const SeedRec *sr = s + soff[r];
+		const int32_t *ow = owner + soff[r];
+		const unsigned long long ky = skey[c];
+		// chain.c:381-386 is a do-while: the peak is taken unconditionally (even when a better chain already
+		// passed through it), the following records only while nobody visited them, i.e. while owner == k
+		int32_t j = (int32_t)(uint32_t)ky, cnt = 1;
+		{ const int32_t p = sr[j].p; j = p >= 0 ? p >> 2 : -1; }
+		while (j >= 0 && ow[j] == k) {
+			++cnt;
+			const int32_t p = sr[j].p;
+			j = p >= 0 ? p >> 2 : -1;
+		}
+		unsigned long long sc = ky >> 32;
+		bool keep = true;
+		if (j >= 0) {                                               // ran into an older chain: must still gain min_sc
+			keep = (int32_t)(ky >> 32) - sr[j].f >= min_sc;
+			sc = (ky >> 32) - (unsigned long long)(long long)sr[j].f;
+		}
+		keep = keep && cnt >= min_cnt;
+		ccnt[c] = keep ? cnt : 0;
+		cu[c] = sc << 32 | (unsigned long long)(uint32_t)cnt;
+	}
+}
+
+// B8: per read (one wave each), positions of the kept chains in rank order and of their anchors
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_layout(int64_t n_reads, const int64_t *__restrict__ ends_off,
+                                                        const int32_t *__restrict__ ccnt, int32_t *__restrict__ kpos,
+                                                        int32_t *__restrict__ bpos, unsigned long long *__restrict__ read_tot)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t wave0 = (int64_t)blockIdx.x * (BT_BLOCK >> 6) + (threadIdx.x >> 6);
+	const int64_t n_waves = (int64_t)gridDim.x * (BT_BLOCK >> 6);
+	for (int64_t r = wave0; r < n_reads; r += n_waves) {
+		const int64_t b = ends_off[r], n = ends_off[r + 1] - b;
+		unsigned int kc = 0, ac = 0;
+		for (int64_t t0 = 0; t0 < n; t0 += 64) {
+			const int64_t e = t0 + lane;
+			const int cnt = e < n ? ccnt[b + e] : 0;
+			const uint64_t km = __builtin_amdgcn_ballot_w64(cnt > 0);
+			const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+			unsigned int incl = (unsigned int)cnt;
+			for (int d = 1; d < 64; d <<= 1) { const unsigned int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+			if (cnt > 0) { kpos[b + e] = (int32_t)(kc + __builtin_popcountll(km & below)); bpos[b + e] = (int32_t)(ac + incl - cnt); }
+			kc += __builtin_popcountll(km);
+			ac += __shfl(incl, 63, 64);
+		}
+		if (lane == 0) read_tot[r] = (unsigned long long)ac << 32 | kc;
+	}
+}
+
+// after the scan of read_tot: chains_off / b_off (int64, n_reads + 1 entries)
+__global__ void k_bt_offsets(int64_t n_reads, const unsigned long long *__restrict__ read_base, const unsigned long long *__restrict__ total,
+                             int64_t *__restrict__ chains_off, int64_t *__restrict__ b_off)
+{
+	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_reads; r += (int64_t)gridDim.x * blockDim.x) {
+		const unsigned long long v = r < n_reads ? read_base[r] : *total;
+		chains_off[r] = (int64_t)(uint32_t)v;
+		b_off[r] = (int64_t)(v >> 32);
+	}
+}
+
+// B9: kept chains, still in rank order: anchors (ascending along the chain), u, and the sort keys of chain.c:412-416
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_emit(int64_t n_reads, const int64_t *__restrict__ soff, const SeedRec *__restrict__ s,
+                                                      const int64_t *__restrict__ ends_off, const unsigned long long *__restrict__ skey,
+                                                      const int32_t *__restrict__ ccnt, const unsigned long long *__restrict__ cu,
+                                                      const int32_t *__restrict__ kpos, const int32_t *__restrict__ bpos,
+                                                      const int64_t *__restrict__ chains_off, const int64_t *__restrict__ b_off,
+                                                      ulonglong2 *__restrict__ b_tmp, unsigned long long *__restrict__ u_tmp,
+                                                      ulonglong2 *__restrict__ w)
+{
+	const int64_t n_e = ends_off[n_reads];
+	for (int64_t c = (int64_t)blockIdx.x * BT_BLOCK + threadIdx.x; c < n_e; c += (int64_t)gridDim.x * BT_BLOCK) {
+		const int32_t cnt = ccnt[c];
+		if (cnt <= 0) continue;
+		const int64_t r = bt_read_of(ends_off, 0, n_reads - 1, c);
+		const SeedRec *sr = s + soff[r];
+		ulonglong2 *dst = b_tmp + b_off[r] + bpos[c];
+		int32_t j = (int32_t)(uint32_t)skey[c];
+		unsigned long long first_x = 0;
+		for (int32_t t = cnt - 1; t >= 0; --t) {                    // chain.c:404-406: reversed walk order
+			const SeedRec rec = sr[j];
+			dst[t] = make_ulonglong2(rec.x, rec.y);
+			first_x = rec.x;
+			j = rec.p >= 0 ? rec.p >> 2 : -1;
+		}
+		const int64_t ck = chains_off[r] + kpos[c];
+		u_tmp[ck] = cu[c];
+		w[ck] = make_ulonglong2(first_x, (unsigned long long)(uint32_t)bpos[c] << 32 | (unsigned long long)(uint32_t)kpos[c]);
+	}
+}
+
+// ---- ksort.h:101-151, radix_sort_128x, restated for one sequential thread (the order it gives equal keys is part
+// of the reference's output)
+__device__ void bt_insertion(ulonglong2 *beg, ulonglong2 *end)
+{
+	for (ulonglong2 *i = beg + 1; i < end; ++i) {
+		if (i->x < (i - 1)->x) {
+			const ulonglong2 tmp = *i;
+			ulonglong2 *j = i;
+			while (j > beg && tmp.x < (j - 1)->x) { *j = *(j - 1); --j; }
+			*j = tmp;
+		}
+	}
+}
+
+struct BtRange { int32_t beg, end, shift; };
+
+__device__ void bt_radix_128x(ulonglong2 *a, int32_t n, BtRange *stack)
+{
+	if (n <= 64) { bt_insertion(a, a + n); return; }
+	int32_t head[256], tail[256];
+	int sp = 0;
+	stack[sp++] = BtRange{0, n, 56};
+	while (sp > 0) {
+		const BtRange rg = stack[--sp];
+		for (int d = 0; d < 256; ++d) tail[d] = 0;
+		for (int32_t q = rg.beg; q < rg.end; ++q) ++tail[a[q].x >> rg.shift & 0xff];
+		int32_t acc = rg.beg;
+		for (int d = 0; d < 256; ++d) { head[d] = acc; acc += tail[d]; tail[d] = acc; }
+		for (int d = 0; d < 256;) {                                 // cycle-leader permutation, buckets in ascending order
+			if (head[d] != tail[d]) {
+				int l = (int)(a[head[d]].x >> rg.shift & 0xff);
+				if (l != d) {
+					ulonglong2 carry = a[head[d]], swap;
+					do {
+						swap = carry; carry = a[head[l]]; a[head[l]++] = swap;
+						l = (int)(carry.x >> rg.shift & 0xff);
+					} while (l != d);
+					a[head[d]++] = carry;
+				} else ++head[d];
+			} else ++d;
+		}
+		if (rg.shift) {
+			const int32_t next = rg.shift > 8 ? rg.shift - 8 : 0;
+			int32_t b = rg.beg;
+			for (int d = 0; d < 256; ++d) {
+				const int32_t e = tail[d];
+				if (e - b > 64) stack[sp++] = BtRange{b, e, next};      // disjoint ranges: the order they are sorted in is immaterial
+				else if (e - b > 1) bt_insertion(a + b, a + e);
+				b = e;
+			}
+		}
+	}
+}
+
+// B10: chains of a read in the reference's final order (chain.c:410-426); one thread per read
+__global__ __launch_bounds__(64) void k_bt_xsort(int64_t n_reads, const int64_t *__restrict__ chains_off, ulonglong2 *__restrict__ w,
+                                                 const unsigned long long *__restrict__ u_tmp, unsigned long long *__restrict__ u_out,
+                                                 int32_t *__restrict__ c_src, int32_t *__restrict__ c_dst, BtRange *__restrict__ stacks)
+{
+	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t b = chains_off[r];
+		const int32_t n = (int32_t)(chains_off[r + 1] - b);
+		if (n <= 0) continue;
+		bt_radix_128x(w + b, n, stacks + b / 64 + 2 * r);           // at most n/65 pending ranges
+		int32_t k = 0;
+		for (int32_t i = 0; i < n; ++i) {
+			const unsigned long long y = w[b + i].y;
+			const unsigned long long u = u_tmp[b + (uint32_t)y];
+			u_out[b + i] = u;
+			c_src[b + i] = (int32_t)(y >> 32);
+			c_dst[b + i] = k;
+			k += (int32_t)(uint32_t)u;
+		}
+	}
+}
+
+// B11: anchors into their final place, one wave per chain
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_copy(int64_t n_reads, const int64_t *__restrict__ chains_off, const int64_t *__restrict__ b_off,
+                                                      const unsigned long long *__restrict__ u_out, const int32_t *__restrict__ c_src,
+                                                      const int32_t *__restrict__ c_dst, const ulonglong2 *__restrict__ b_tmp,
+                                                      ulonglong2 *__restrict__ b_out)
+{
+	const int lane = threadIdx.x & 63;
+	const int64_t n_c = chains_off[n_reads];
+	const int64_t wave0 = (int64_t)blockIdx.x * (BT_BLOCK >> 6) + (threadIdx.x >> 6);
+	const int64_t n_waves = (int64_t)gridDim.x * (BT_BLOCK >> 6);
+	for (int64_t c = wave0; c < n_c; c += n_waves) {
+		const int64_t bb = b_off[bt_read_of(chains_off, 0, n_reads - 1, c)];
+		const int32_t n = (int32_t)(uint32_t)u_out[c];
+		const ulonglong2 *src = b_tmp + bb + c_src[c];
+		ulonglong2 *dst = b_out + bb + c_dst[c];
+		for (int32_t k = lane; k < n; k += 64) dst[k] = src[k];
+	}
+}
+
+static inline unsigned bt_grid(int64_t n, int per)
+{
+	int64_t g = (n + per - 1) / per;
+	if (g < 1) g = 1;
+	if (g > 65535) g = 65535;
+	return (unsigned)g;
+}
+
+hipError_t launch_backtrack(hipStream_t st, int min_cnt, int min_sc, int64_t n_reads, int64_t m_cap, const int64_t *d_soff, const void *d_seeds,
+                            const unsigned long long *d_n_seeds, BottomScratch sc, int64_t n_seeds_host)
+{
+	hipError_t e;
+	const int64_t m = n_seeds_host;
+	(void)m_cap; (void)d_n_seeds;
+	if (n_reads <= 0 || m <= 0) {
+		if ((e = hipMemsetAsync(sc.chains_off, 0, (size_t)(n_reads > 0 ? n_reads + 1 : 1) * 8, st)) != hipSuccess) return e;
+		return hipMemsetAsync(sc.b_off, 0, (size_t)(n_reads > 0 ? n_reads + 1 : 1) * 8, st);
+	}
+	const SeedRec *s = (const SeedRec*)d_seeds;
+	const int64_t blocks = (m + BT_PER_BLOCK - 1) / BT_PER_BLOCK;
+	if ((e = hipMemsetAsync(sc.has, 0, (size_t)m, st)) != hipSuccess) return e;
+	if ((e = hipMemsetAsync(sc.owner, 0x7f, (size_t)m * 4, st)) != hipSuccess) return e;
+	hipLaunchKernelGGL(k_bt_children, dim3(bt_grid(m, BT_BLOCK)), dim3(BT_BLOCK), 0, st, n_reads, m, d_soff, s, sc.has);
+	hipLaunchKernelGGL(k_bt_end_count, dim3((unsigned)blocks), dim3(BT_BLOCK), 0, st, m, s, sc.has, sc.block_cnt);
+	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, sc.total)) != hipSuccess) return e;
+	hipLaunchKernelGGL(k_bt_end_list, dim3((unsigned)blocks), dim3(BT_BLOCK), 0, st, n_reads, m, d_soff, s, sc.has, sc.block_cnt, sc.end_rec, sc.ends_off);
+	hipLaunchKernelGGL(k_bt_close_offsets, dim3(1), dim3(1), 0, st, n_reads, m, d_soff, sc.total, sc.ends_off);
+	const unsigned gE = bt_grid(m, BT_BLOCK);                       // ends <= records
+	hipLaunchKernelGGL(k_bt_peaks, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, d_soff, s, sc.ends_off, sc.end_rec, sc.key);
+	hipLaunchKernelGGL(k_bt_rank, dim3(bt_grid(n_reads, 1)), dim3(BT_BLOCK), 0, st, n_reads, sc.ends_off, sc.key, sc.skey);
+	hipLaunchKernelGGL(k_bt_own, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, d_soff, s, sc.ends_off, sc.skey, sc.owner);
+	hipLaunchKernelGGL(k_bt_score, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, min_cnt, min_sc, d_soff, s, sc.ends_off, sc.skey, sc.owner, sc.ccnt, sc.cu);
+	hipLaunchKernelGGL(k_bt_layout, dim3(bt_grid(n_reads, 4)), dim3(BT_BLOCK), 0, st, n_reads, sc.ends_off, sc.ccnt, sc.kpos, sc.bpos, sc.read_tot);
+	if ((e = launch_scan_u64(st, n_reads, sc.read_tot, sc.tile_tmp, sc.total)) != hipSuccess) return e;
+	hipLaunchKernelGGL(k_bt_offsets, dim3(bt_grid(n_reads + 1, 256)), dim3(256), 0, st, n_reads, sc.read_tot, sc.total, sc.chains_off, sc.b_off);
+	hipLaunchKernelGGL(k_bt_emit, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, d_soff, s, sc.ends_off, sc.skey, sc.ccnt, sc.cu, sc.kpos, sc.bpos,
+	                   sc.chains_off, sc.b_off, (ulonglong2*)sc.b_tmp, sc.u_tmp, (ulonglong2*)sc.w);
+	hipLaunchKernelGGL(k_bt_xsort, dim3(bt_grid(n_reads, 64)), dim3(64), 0, st, n_reads, sc.chains_off, (ulonglong2*)sc.w, sc.u_tmp, sc.u_out,
+	                   sc.c_src, sc.c_dst, (BtRange*)sc.stacks);
+	hipLaunchKernelGGL(k_bt_copy, dim3(bt_grid(m, 64)), dim3(BT_BLOCK), 0, st, n_reads, sc.chains_off, sc.b_off, sc.u_out, sc.c_src, sc.c_dst,
+	                   (const ulonglong2*)sc.b_tmp, (ulonglong2*)sc.b_out);
+	return hipGetLastError();
+}
+
+} // namespace chaindp

@@ -61,6 +61,19 @@ hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, in
                           int32_t *d_first_child, int32_t *d_id, int64_t *d_seeds_off, void *d_seeds,
                           CompactScratch sc);
 
+// mm_chain_dp_bottom (reference chain.c:329-431) on the GPU: chaindp_bottom.hip.  m = records of the batch.
+struct BottomScratch {
+	uint8_t *has;                    // m
+	int32_t *owner, *end_rec, *ccnt, *kpos, *bpos, *c_src, *c_dst;   // m each
+	unsigned long long *key, *skey, *cu, *u_tmp, *u_out;             // m each
+	void *b_tmp, *b_out, *w;         // m x 16 B each
+	void *stacks;                    // (m/64 + 2 R + 4) x 12 B
+	unsigned long long *block_cnt, *tile_tmp, *read_tot, *total;     // m/1024+1, same, R, 1
+	int64_t *ends_off, *chains_off, *b_off;                          // R+1 each
+};
+hipError_t launch_backtrack(hipStream_t st, int min_cnt, int min_sc, int64_t n_reads, int64_t m_cap, const int64_t *d_soff, const void *d_seeds,
+                            const unsigned long long *d_n_seeds, BottomScratch sc, int64_t n_seeds_host);
+
 // zero-copy movement between device-visible (pinned) host buffers and HBM: chaindp_io.hip
 hipError_t launch_gather_reads(hipStream_t st, int64_t n_reads, const int64_t *d_off, const void *const *d_src, void *d_a);
 hipError_t launch_scatter_seeds(hipStream_t st, int64_t n_reads, const int64_t *d_seeds_off, void *const *d_dst, const void *d_seeds);
