@@ -178,6 +178,25 @@ def measure_extras(torch, dev, par, off, anchors, total):
     dt = time.perf_counter() - t0
     ex["end_to_end"] = {"anchors_per_s": total / dt, "seconds": dt,
                         "includes": "H2D of anchors, prepass + chain DP + compaction, D2H of f/p/v and new_seed[] (pageable host buffers)"}
+    # the host half (mm_chain_dp_bottom, chain.c:329-431) on the GPU as well, timed on its own
+    try:
+        dev.set_profiling(True); dev.kernel_ms(reset=True)
+        t0 = time.perf_counter()
+        coff, u, boff, b = dev.backtrack(par, 3)
+        dt_bt = time.perf_counter() - t0
+        kb = dev.kernel_ms(reset=True)["backtrack"]
+        dev.set_profiling(False)
+        ex["backtrack"] = {"kernels_ms": kb[0] / max(kb[1], 1), "with_download_s": dt_bt, "chains": int(coff[-1]),
+                           "chained_anchors": int(boff[-1]), "anchors_per_s_kernels": total / (kb[0] / max(kb[1], 1) * 1e-3)}
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as ol
+        k = min(400, len(soff) - 1)
+        t0 = time.perf_counter()
+        for r in range(k):
+            ol.oracle_bottom(3, par.min_sc, seeds[int(soff[r]):int(soff[r + 1])])
+        ex["backtrack"]["cpu_port_1core_anchors_per_s"] = int(off[k]) / (time.perf_counter() - t0)
+    except Exception as e:  # noqa: BLE001
+        ex["backtrack"] = {"error": str(e)}
     n = 1 << 28                                                  # 1 GiB of int32 each way
     src = torch.empty(n, dtype=torch.int32, device="cuda")
     dst = torch.empty_like(src)

@@ -138,10 +138,10 @@ int chaindp_run_device(chaindp_ctx_t *ctx, const chaindp_params_t *par, int64_t 
 /* ---- measurement ----------------------------------------------------------------------
  * With profiling on, every run brackets each kernel with HIP events on the stream it is
  * launched on; the accumulated device times are read back (after chaindp_sync) here.
- * ms[0] = prepass kernel, ms[1] = chain DP kernel, ms[2] = compaction kernels;
+ * ms[0] = prepass kernels, ms[1] = chain DP kernel, ms[2] = compaction kernels, ms[3] = backtrack kernels;
  * launches[i] = number of launches accumulated.  reset != 0 clears the accumulators. */
 int chaindp_set_profiling(chaindp_ctx_t *ctx, int on);
-int chaindp_get_kernel_ms(chaindp_ctx_t *ctx, double ms[3], int64_t launches[3], int reset);
+int chaindp_get_kernel_ms(chaindp_ctx_t *ctx, double ms[4], int64_t launches[4], int reset);
 
 /* Work decomposition of the last run: st[0] = units (independent DP problems, >= 2 anchors),
  * st[1] = singleton anchors resolved in the prepass, st[2] = anchors, st[3] = reads. */

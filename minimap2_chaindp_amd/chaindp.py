@@ -197,10 +197,10 @@ class Device:
 
     def kernel_ms(self, reset=False):
         """Accumulated HIP-event device time per kernel: dict name -> (ms, launches)."""
-        ms = (C.c_double * 3)()
-        n = (C.c_int64 * 3)()
+        ms = (C.c_double * 4)()
+        n = (C.c_int64 * 4)()
         self._check(self._lib.chaindp_get_kernel_ms(self._ctx, ms, n, int(reset)))
-        return {k: (ms[i], n[i]) for i, k in enumerate(("prepass", "chain_dp", "compact"))}
+        return {k: (ms[i], n[i]) for i, k in enumerate(("prepass", "chain_dp", "compact", "backtrack"))}
 
     def stats(self):
         st = (C.c_int64 * 4)()

@@ -51,8 +51,8 @@ struct chaindp_ctx {
 	// profiling
 	bool prof = false;
 	std::vector<EventSet> pending;
-	double ms[3] = {0, 0, 0};
-	int64_t launches[3] = {0, 0, 0};
+	double ms[4] = {0, 0, 0, 0};
+	int64_t launches[4] = {0, 0, 0, 0};
 	int64_t stats[4] = {0, 0, 0, 0};
 	std::string err;
 };
@@ -378,8 +378,15 @@ extern "C" int chaindp_backtrack(chaindp_ctx_t *ctx, const chaindp_params_t *par
 		HIP_TRY(ctx, bot_alloc(ctx, s.read_tot, (R + 2) * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.total, 8));
 		HIP_TRY(ctx, bot_alloc(ctx, s.ends_off, (R + 2) * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.chains_off, (R + 2) * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.b_off, (R + 2) * 8));
 	}
+	EventSet es; es.n = 0; es.slot0 = 3;
+	if (ctx->prof) {
+		for (int k = 0; k < 2; ++k) HIP_TRY(ctx, hipEventCreate(&es.e[k]));
+		es.n = 2;
+		HIP_TRY(ctx, hipEventRecord(es.e[0], ctx->stream));
+	}
 	HIP_TRY(ctx, chaindp::launch_backtrack(ctx->stream, min_cnt, par->min_sc, ctx->n_reads, ctx->cap_anchors, ctx->d_seeds_off, ctx->d_seeds,
 	                                       ctx->cmp.n_seeds, ctx->bot, m));
+	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[1], ctx->stream)); ctx->pending.push_back(es); }
 	const size_t ob = (size_t)(ctx->n_reads > 0 ? ctx->n_reads + 1 : 1) * 8;
 	HIP_TRY(ctx, hipMemcpyAsync(chains_off, ctx->bot.chains_off, ob, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipMemcpyAsync(b_off, ctx->bot.b_off, ob, hipMemcpyDeviceToHost, ctx->stream));
@@ -547,7 +554,7 @@ extern "C" void chaindp_host_free(void *p)
 	if (p) hipHostFree(p);
 }
 
-extern "C" int chaindp_get_kernel_ms(chaindp_ctx_t *ctx, double ms[3], int64_t launches[3], int reset)
+extern "C" int chaindp_get_kernel_ms(chaindp_ctx_t *ctx, double ms[4], int64_t launches[4], int reset)
 {
 	if (!ctx) return CHAINDP_ERR_ARG;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -562,8 +569,8 @@ extern "C" int chaindp_get_kernel_ms(chaindp_ctx_t *ctx, double ms[3], int64_t l
 		for (int k = 0; k < es.n; ++k) hipEventDestroy(es.e[k]);
 	}
 	ctx->pending.clear();
-	for (int k = 0; k < 3; ++k) { if (ms) ms[k] = ctx->ms[k]; if (launches) launches[k] = ctx->launches[k]; }
-	if (reset) for (int k = 0; k < 3; ++k) { ctx->ms[k] = 0; ctx->launches[k] = 0; }
+	for (int k = 0; k < 4; ++k) { if (ms) ms[k] = ctx->ms[k]; if (launches) launches[k] = ctx->launches[k]; }
+	if (reset) for (int k = 0; k < 4; ++k) { ctx->ms[k] = 0; ctx->launches[k] = 0; }
 	return CHAINDP_OK;
 }
 
