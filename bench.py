@@ -112,7 +112,7 @@ def main():
         dist.barrier()
 
     extras = {}
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:      # side measurements only in the single-GPU run
         extras = measure_extras(torch, dev, par, off, anchors, total)
 
     if rank == 0:
