@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--reads-per-gpu", type=int, default=READS_PER_GPU)
     ap.add_argument("--preset", default="ava-ont", help="generator + DP preset (ava-ont, map-ont, skew)")
     ap.add_argument("--ring", type=int, default=0, help="LDS ring capacity override (128/256/512)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed side measurements (end-to-end rate, copy bandwidth, pair evaluations)")
     ap.add_argument("--cpu-sample-anchors", type=int, default=40_000_000)
@@ -65,9 +66,16 @@ def main():
 
     if not torch.cuda.is_available() or chaindp.device_count() <= 0:
         raise SystemExit("bench.py needs a GPU: the chaining DP has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit(f"LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible")
+    dev_index = local_rank % n_dev                       # one GPU per rank; several ranks share one only in a gloo rehearsal
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
 
     gen_preset = args.preset
     dp_preset = args.preset if args.preset in params.PRESETS else "ava-ont"      # skew / dense / ties use ava-ont gaps
@@ -79,7 +87,7 @@ def main():
     off, anchors = shard.generate_shard(gen_preset, rank, world, n_reads, SEED, threads=args.host_threads)
     t_gen = time.time() - t_gen
     total = int(off[-1])
-    dev = chaindp.Device(local_rank, max_anchors=total + 1, max_reads=n_reads + 1, ring=args.ring or None)
+    dev = chaindp.Device(dev_index, max_anchors=total + 1, max_reads=n_reads + 1, ring=args.ring or None)
     t_up = time.time()
     dev.upload(off, anchors)
     t_up = time.time() - t_up
@@ -107,7 +115,8 @@ def main():
     stats = dev.stats()
 
     # max over ranks of the timed region; sum of anchors
-    elapsed_max, total_all = shard.reduce_job(elapsed, total, dist if world > 1 else None, device="cuda")
+    elapsed_max, total_all = shard.reduce_job(elapsed, total, dist if world > 1 else None,
+                                              device="cuda" if args.backend == "nccl" else None)
     if world > 1:
         dist.barrier()
 

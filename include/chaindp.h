@@ -54,9 +54,9 @@ typedef struct chaindp_ctx chaindp_ctx_t;
 /* Number of HIP devices visible to the process (0 when there is none). */
 int chaindp_device_count(void);
 
-/* One context per (host thread, GPU): owns a stream, device buffers for up to
- * max_anchors anchors / max_reads reads, and pinned host staging of the same size.
- * Returns NULL on failure (no device, out of memory). */
+/* One context per (host thread, GPU): owns a stream and the device buffers for batches of up to
+ * max_anchors anchors / max_reads reads (both at most 2^31-1; about 80 bytes of HBM per anchor).
+ * Returns NULL on failure (no device, out of memory, bad arguments): chaindp_last_error(NULL) says why. */
 chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_t max_reads);
 void chaindp_destroy(chaindp_ctx_t *ctx);
 const char *chaindp_last_error(const chaindp_ctx_t *ctx);   /* ctx may be NULL: last create() error */

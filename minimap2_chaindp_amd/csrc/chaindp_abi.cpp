@@ -101,14 +101,14 @@ extern "C" const char *chaindp_last_error(const chaindp_ctx_t *ctx)
 extern "C" void chaindp_destroy(chaindp_ctx_t *ctx)
 {
 	if (!ctx) return;
-	if (ctx->device >= 0) hipSetDevice(ctx->device);
-	if (ctx->stream) hipStreamSynchronize(ctx->stream);
-	for (auto &es : ctx->pending) for (int k = 0; k < es.n; ++k) hipEventDestroy(es.e[k]);
+	if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	for (auto &es : ctx->pending) for (int k = 0; k < es.n; ++k) (void)hipEventDestroy(es.e[k]);
 	void *bufs[] = {ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_sumq, ctx->d_units,
 	                ctx->d_counters, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
-	for (void *b : bufs) if (b) hipFree(b);
-	for (void *b : ctx->bot_allocs) if (b) hipFree(b);
-	if (ctx->stream) hipStreamDestroy(ctx->stream);
+	for (void *b : bufs) if (b) (void)hipFree(b);
+	for (void *b : ctx->bot_allocs) if (b) (void)hipFree(b);
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
 
@@ -551,7 +551,7 @@ extern "C" void *chaindp_host_alloc(size_t bytes)
 
 extern "C" void chaindp_host_free(void *p)
 {
-	if (p) hipHostFree(p);
+	if (p) (void)hipHostFree(p);
 }
 
 extern "C" int chaindp_get_kernel_ms(chaindp_ctx_t *ctx, double ms[4], int64_t launches[4], int reset)
@@ -566,7 +566,7 @@ extern "C" int chaindp_get_kernel_ms(chaindp_ctx_t *ctx, double ms[4], int64_t l
 			ctx->ms[es.slot0 + k] += (double)t;
 			ctx->launches[es.slot0 + k] += 1;
 		}
-		for (int k = 0; k < es.n; ++k) hipEventDestroy(es.e[k]);
+		for (int k = 0; k < es.n; ++k) (void)hipEventDestroy(es.e[k]);
 	}
 	ctx->pending.clear();
 	for (int k = 0; k < 4; ++k) { if (ms) ms[k] = ctx->ms[k]; if (launches) launches[k] = ctx->launches[k]; }

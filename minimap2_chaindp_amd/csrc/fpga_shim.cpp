@@ -30,8 +30,6 @@ static_assert(sizeof(chaindp_seed_t) == 24, "struct new_seed must be 24 bytes");
 
 namespace {
 
-struct Buf { void *p; size_t cap; };
-
 // Pinned buffers in power-of-two size classes, recycled.
 class PinnedPool {
 public:
@@ -62,7 +60,7 @@ public:
 	void destroy()
 	{
 		std::lock_guard<std::mutex> g(mu_);
-		for (auto &kv : cap_of_) hipHostFree(kv.first);
+		for (auto &kv : cap_of_) (void)hipHostFree(kv.first);
 		cap_of_.clear(); free_.clear();
 	}
 private:

@@ -68,14 +68,14 @@ static void wm_unit(const co_params_t *par, float avg, const co_anchor_t *a, int
 		for (c = 0; !done; ++c) {
 			const int in_ring_chunk = (c + 1) * W <= ring;
 			int32_t sc[W], incl[W], S[W], M[W], pj[W];
-			uint8_t live[W], valid[W], Abit[W], Bbit[W];
+			uint8_t valid[W], Abit[W], Bbit[W];
 			int k, kb = -1, all_live = 1, cntA = 0, cntB = 0, a_after_b = 0, seen_b = 0;
 			++st->chunks;
 			if (!in_ring_chunk) ++st->deep_chunks;
 			/* filters (chain.c:252-261) and base score (chain.c:262-273), all lanes at once */
 			for (k = 0; k < W; ++k) {
 				const int64_t j = i - 1 - c * W - k;
-				live[k] = valid[k] = 0; sc[k] = INT_MIN; pj[k] = -1;
+				valid[k] = 0; sc[k] = INT_MIN; pj[k] = -1;
 				if (j < u0) { all_live = 0; continue; }
 				{
 					const uint64_t d64 = ri - a[j].x;
@@ -84,7 +84,7 @@ static void wm_unit(const co_params_t *par, float avg, const co_anchor_t *a, int
 					int64_t dr;
 					int32_t dd, s0;
 					if (d64 > maxx) { all_live = 0; continue; }
-					live[k] = 1; ++st->lane_evals;
+					++st->lane_evals;
 					dr = (int64_t)d64;
 					pj[k] = p[j];
 					if ((same && dr == 0) || dq <= 0) continue;

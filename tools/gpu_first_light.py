@@ -1,7 +1,7 @@
 """Quick device-side timing used while bringing the kernels up (not a test, not the benchmark)."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
 import numpy as np
 from minimap2_chaindp_amd import anchorgen as ag, chaindp, params as P
 
