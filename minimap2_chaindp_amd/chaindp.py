@@ -12,7 +12,8 @@ import numpy as np
 from .params import ChainParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libchaindp_hip.so")
+# CHAINDP_LIB: an alternative build of the same library (A/B timing of kernel variants on one box, tools/ab.sh)
+LIB_PATH = os.environ.get("CHAINDP_LIB") or os.path.join(_HERE, "csrc", "libchaindp_hip.so")
 
 SEED_DTYPE = np.dtype([("x", "<u8"), ("y", "<u8"), ("p", "<i4"), ("f", "<i4")])  # struct new_seed (minimap.h:51-55)
 
