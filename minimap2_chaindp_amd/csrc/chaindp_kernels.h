@@ -16,7 +16,7 @@ struct Params {
 struct Unit {
 	int64_t start;   // global anchor index
 	int32_t read;
-	int32_t pad;
+	int32_t len;     // upper bound of its length (next unit's start or end of the read)
 };
 
 // prepass scratch: one 64-bit unit-start mask per 64 anchors, per-block unit / singleton counts
@@ -24,6 +24,8 @@ struct PrepassScratch {
 	uint64_t *start_mask;
 	unsigned long long *block_cnt;   // per 1024-anchor block: units | singletons << 32; scanned in place
 	unsigned long long *tile_tmp;    // scratch of the scan
+	Unit *units_tmp;                 // units in anchor order, before the longest-first scatter
+	unsigned int *hist;              // 2 x 128: length-class histogram / bases, cursors
 };
 size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *blocks_bytes);
 

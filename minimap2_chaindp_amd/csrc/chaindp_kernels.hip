@@ -209,26 +209,92 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_rea
 	}
 }
 
+// Units are scheduled longest first (a unit is one wave's serial work, so a long one started last would be the
+// kernel's tail): 128 length classes, class-descending order, order inside a class immaterial.
+#define UNIT_CLASSES 128
+__device__ __forceinline__ int unit_class(int32_t len)
+{
+	if (len < 4096) return len >> 6;                         // 0..63: 64-anchor steps
+	const int c = 64 + (len >> 12);                          // 65..: 4096-anchor steps
+	return c < UNIT_CLASSES ? c : UNIT_CLASSES - 1;
+}
+
 __global__ __launch_bounds__(256) void k_emit_units(int64_t n_reads, int64_t n_words, const int64_t *__restrict__ off,
                                                     const uint64_t *__restrict__ start_mask,
-                                                    const unsigned long long *__restrict__ block_base, Unit *__restrict__ units)
+                                                    const unsigned long long *__restrict__ block_base, Unit *__restrict__ units,
+                                                    unsigned int *__restrict__ hist)
 {
+	__shared__ unsigned int s_hist[UNIT_CLASSES];
+	if (threadIdx.x < UNIT_CLASSES) s_hist[threadIdx.x] = 0;
+	__syncthreads();
 	const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (w >= n_words) return;
-	uint64_t m = start_mask[w];
-	if (!m) return;
-	const int64_t b = w / PRE_WORDS;
-	uint64_t pos = (uint32_t)block_base[b];                 // low word: units before this block
-	for (int64_t k = b * PRE_WORDS; k < w; ++k) pos += (uint64_t)__builtin_popcountll(start_mask[k]);
-	int64_t r = read_of(off, 0, n_reads - 1, w << 6);
-	while (m) {
-		const int bit = __builtin_ctzll(m);
-		m &= m - 1;
-		const int64_t g = (w << 6) + bit;
-		while (g >= off[r + 1]) ++r;            // units of one word are in anchor order; reads only move forward
-		Unit u;
-		u.start = g; u.read = (int32_t)r; u.pad = 0;
-		units[pos++] = u;
+	uint64_t m = w < n_words ? start_mask[w] : 0;
+	if (m) {
+		const int64_t b = w / PRE_WORDS;
+		uint64_t pos = (uint32_t)block_base[b];             // low word: units before this block
+		for (int64_t k = b * PRE_WORDS; k < w; ++k) pos += (uint64_t)__builtin_popcountll(start_mask[k]);
+		int64_t r = read_of(off, 0, n_reads - 1, w << 6);
+		while (m) {
+			const int bit = __builtin_ctzll(m);
+			m &= m - 1;
+			const int64_t g = (w << 6) + bit;
+			while (g >= off[r + 1]) ++r;                    // units of one word are in anchor order; reads only move forward
+			const int64_t re = off[r + 1];
+			// upper bound of the unit: the next unit's start or the end of the read (singletons in between are
+			// not units, so this can overshoot the true end; the DP kernel finds the true end itself)
+			int64_t next = -1;
+			if (m) next = (w << 6) + __builtin_ctzll(m);
+			else for (int64_t k = w + 1; k < n_words && (k << 6) < re; ++k) {
+				const uint64_t mm = start_mask[k];
+				if (mm) { next = (k << 6) + __builtin_ctzll(mm); break; }
+			}
+			const int64_t end = next >= 0 && next < re ? next : re;
+			Unit u;
+			u.start = g; u.read = (int32_t)r; u.len = (int32_t)(end - g);
+			units[pos++] = u;
+			atomicAdd(&s_hist[unit_class(u.len)], 1u);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < UNIT_CLASSES && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
+}
+
+// hist[c] -> first position of class c in the longest-first order; cursor[c] = 0
+__global__ void k_unit_bases(unsigned int *__restrict__ hist, unsigned int *__restrict__ cursor)
+{
+	if (threadIdx.x == 0) {
+		unsigned int acc = 0;
+		for (int c = UNIT_CLASSES - 1; c >= 0; --c) { const unsigned int n = hist[c]; hist[c] = acc; acc += n; cursor[c] = 0; }
+	}
+}
+
+// scatter into class order: ranks inside a block come from LDS atomics, one global atomic per (block, class)
+// reserves the block's range (a global atomic per wave and class on the handful of hot classes cost 0.45 ms)
+#define SCAT_PER_THREAD 4
+__global__ __launch_bounds__(256) void k_unit_scatter(const unsigned long long *__restrict__ counters, const Unit *__restrict__ in,
+                                                      const unsigned int *__restrict__ base, unsigned int *__restrict__ cursor,
+                                                      Unit *__restrict__ out)
+{
+	__shared__ unsigned int s_cnt[UNIT_CLASSES], s_base[UNIT_CLASSES];
+	const int64_t n = (int64_t)(uint32_t)counters[0];
+	const int64_t per_block = 256 * SCAT_PER_THREAD;
+	for (int64_t b0 = (int64_t)blockIdx.x * per_block; b0 < n; b0 += (int64_t)gridDim.x * per_block) {
+		if (threadIdx.x < UNIT_CLASSES) s_cnt[threadIdx.x] = 0;
+		__syncthreads();
+		Unit u[SCAT_PER_THREAD];
+		int cls[SCAT_PER_THREAD];
+		unsigned int rank[SCAT_PER_THREAD];
+		for (int k = 0; k < SCAT_PER_THREAD; ++k) {
+			const int64_t i = b0 + k * 256 + threadIdx.x;
+			cls[k] = -1;
+			if (i < n) { u[k] = in[i]; cls[k] = unit_class(u[k].len); rank[k] = atomicAdd(&s_cnt[cls[k]], 1u); }
+		}
+		__syncthreads();
+		if (threadIdx.x < UNIT_CLASSES && s_cnt[threadIdx.x])
+			s_base[threadIdx.x] = base[threadIdx.x] + atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]);
+		__syncthreads();
+		for (int k = 0; k < SCAT_PER_THREAD; ++k) if (cls[k] >= 0) out[s_base[cls[k]] + rank[k]] = u[k];
+		__syncthreads();
 	}
 }
 
@@ -612,11 +678,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 			for (int k = lane; k < RING; k += 64) *(uint4*)(c.s_w + 4 * k) = make_uint4(x_none, 0u, 0u, 0xffffffffu);
 		}
 		wave_mem_fence();
-		// units are emitted in anchor order, so the next unit's start bounds this one (tile prefetch stops there)
-		int64_t lim = re;
-		if (ub + 1 < n_units) { const int64_t nxt = units[ub + 1].start; lim = nxt < re && nxt > u.start ? nxt : re; }
-		if (general) run_unit<RING, true>(c, lim - u.start);
-		else run_unit<RING, false>(c, lim - u.start);
+		// u.len bounds the unit (next unit's start or the read's end); run_unit finds the true end at the first gap
+		if (general) run_unit<RING, true>(c, (int64_t)u.len);
+		else run_unit<RING, false>(c, (int64_t)u.len);
 	}
 }
 
@@ -635,8 +699,12 @@ hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, in
 	hipLaunchKernelGGL(k_prepass, dim3((unsigned)blocks), dim3(PRE_BLOCK), 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a,
 	                   d_sumq, sc.start_mask, sc.block_cnt, d_f, d_p, d_v, d_tg, d_flags);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, d_counters)) != hipSuccess) return e;
+	if ((e = hipMemsetAsync(sc.hist, 0, 2 * UNIT_CLASSES * sizeof(unsigned int), st)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_emit_units, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, n_reads, words, d_off,
-	                   sc.start_mask, sc.block_cnt, d_units);
+	                   sc.start_mask, sc.block_cnt, sc.units_tmp, sc.hist);
+	hipLaunchKernelGGL(k_unit_bases, dim3(1), dim3(64), 0, st, sc.hist, sc.hist + UNIT_CLASSES);
+	hipLaunchKernelGGL(k_unit_scatter, dim3((unsigned)(blocks < 1024 ? (blocks > 0 ? blocks : 1) : 1024)), dim3(256), 0, st, d_counters, sc.units_tmp,
+	                   sc.hist, sc.hist + UNIT_CLASSES, d_units);
 	return hipGetLastError();
 }
 
