@@ -6,5 +6,7 @@ this package is its host-side mirror for tests and benchmarks:
   fpga       the reference's packet-level driver ABI (fpga.h) as served by the library
   params     DP parameter presets as the reference derives them
   anchorgen  seeded ONT-shaped synthetic anchor batches
+  shard      read sharding across the GPUs of a node
+  dump       anchor-dump files produced from real reads by the reference's own front half (oracle/mt_dump.c)
 """
-__all__ = ["chaindp", "fpga", "params", "anchorgen", "shard"]
+__all__ = ["chaindp", "fpga", "params", "anchorgen", "shard", "dump"]

@@ -91,3 +91,20 @@ def test_presets_follow_options_c():
     assert P.preset("map-ont").astuple() == (5000, 5000, 500, 25, 40, 0, 1)     # options.c:29-34,95-96
     assert P.preset("ava-ont").astuple() == (10000, 10000, 500, 25, 100, 0, 1)  # options.c:84-87
     assert P.preset("ava-pb").bw == 2000                                        # options.c:92
+
+
+def test_anchor_dump_roundtrip_and_reference_dumps(tmp_path):
+    """dumps written by oracle/mt_dump.c (the reference's own sketch/index/collect_seed_hits on its
+    test/*.fa) load, regroup into batches and survive a write/read round trip."""
+    from minimap2_chaindp_amd import dump
+    d = os.path.join(ROOT, "tests", "golden", "dumps")
+    mt = dump.read_dump(os.path.join(d, "mt_orang_vs_human.mapont.dump"))
+    assert len(mt) == 1 and mt[0][0].astuple() == (5000, 5000, 500, 25, 40, 0, 1) and mt[0][1] == 3 and mt[0][2].shape == (346, 2)
+    inv = dump.read_dump(os.path.join(d, "q_inv_vs_t_inv.mapont.dump"))
+    assert len(inv) == 2
+    b = dump.batches(mt + inv)
+    assert len(b) == 1 and list(b[0][2]) == [0, 346, 346 + inv[0][2].shape[0], 346 + inv[0][2].shape[0] + inv[1][2].shape[0]]
+    p = tmp_path / "x.dump"
+    dump.write_dump(p, mt + inv)
+    again = dump.read_dump(p)
+    assert all(np.array_equal(x[2], y[2]) and x[0].astuple() == y[0].astuple() for x, y in zip(mt + inv, again))

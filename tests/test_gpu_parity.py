@@ -156,3 +156,30 @@ def test_run_is_idempotent_and_staged_api(dev):
     assert np.array_equal(f1, f2) and np.array_equal(p1, p2) and np.array_equal(v1, v2)
     st = dev.stats()
     assert st["anchors"] == int(off[-1]) and st["reads"] == 50 and st["units"] > 0
+
+
+def test_reference_anchor_dumps_chain_like_the_oracle(dev):
+    """Real-read dumps (oracle/mt_dump.c: the reference's own front half on its test/*.fa) through
+    the GPU, with each read's own DP arguments."""
+    import os
+    from minimap2_chaindp_amd import dump
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dumps")
+    reads = []
+    for fn in sorted(os.listdir(d)):
+        reads += dump.read_dump(os.path.join(d, fn))
+    assert len(reads) == 3
+    dev.set_ring(128)
+    for par, min_cnt, off, a, idx in dump.batches(reads):
+        f, p, v = dev.chain_batch(par, off, a)
+        of, op, ov, _ = ol.oracle_batch(par, off, a, threads=2)
+        assert np.array_equal(f, of) and np.array_equal(p, op) and np.array_equal(v, ov)
+        soff, seeds = dev.compact(par)
+        coff, u, boff, b = dev.backtrack(par, min_cnt)
+        for r in range(len(off) - 1):
+            eu, eb = ol.oracle_bottom(min_cnt, par.min_sc, seeds[int(soff[r]):int(soff[r + 1])])
+            assert np.array_equal(u[int(coff[r]):int(coff[r + 1])], eu) and np.array_equal(b[int(boff[r]):int(boff[r + 1])], eb.reshape(-1, 2))
+    # the MT read is BASELINE config 1: one chain, score 3189, 342 anchors
+    mt = [x for x in reads if x[2].shape[0] == 346][0]
+    dev.chain_batch(mt[0], np.array([0, 346], np.int64), mt[2]); dev.compact(mt[0])
+    coff, u, boff, b = dev.backtrack(mt[0], mt[1])
+    assert len(u) == 1 and int(u[0]) >> 32 == 3189 and int(u[0]) & 0xffffffff == 342
