@@ -151,6 +151,61 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_rank(int64_t n_reads, const int
 	}
 }
 
+// Reads whose records fit the LDS (BT_LDS_RECS of them: p and owner, 8 B each) get B6+B7 from one workgroup
+// working in LDS (k_bt_read_lds); the global-memory kernels below only serve the longer reads.
+#define BT_LDS_RECS 8192
+
+// B6+B7 for one read per workgroup, in LDS: owner by LDS atomicMin walkers (one thread per chain), then length,
+// score and fate of every chain.  Scattered returning atomics in HBM are ~9 G/s chip-wide; in LDS they cost ~100 cycles.
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_read_lds(int64_t n_reads, int min_cnt, int min_sc, const int64_t *__restrict__ soff,
+                                                          const SeedRec *__restrict__ s, const int64_t *__restrict__ ends_off,
+                                                          const unsigned long long *__restrict__ skey,
+                                                          int32_t *__restrict__ ccnt, unsigned long long *__restrict__ cu)
+{
+	extern __shared__ int32_t bt_lds[];
+	int32_t *s_p = bt_lds, *s_own = bt_lds + BT_LDS_RECS;
+	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+		const int64_t so = soff[r];
+		const int32_t m = (int32_t)(soff[r + 1] - so);
+		const int64_t cb = ends_off[r];
+		const int32_t nc = (int32_t)(ends_off[r + 1] - cb);
+		if (m <= 0 || m > BT_LDS_RECS || nc <= 0) continue;
+		const SeedRec *sr = s + so;
+		__syncthreads();
+		for (int32_t j = threadIdx.x; j < m; j += BT_BLOCK) { s_p[j] = sr[j].p; s_own[j] = 0x7fffffff; }
+		__syncthreads();
+		for (int32_t k = threadIdx.x; k < nc; k += BT_BLOCK) {          // walkers: rank k claims its path until a better rank owns it
+			int32_t j = (int32_t)(uint32_t)skey[cb + k];
+			while (j >= 0) {
+				if (atomicMin(&s_own[j], k) < k) break;
+				const int32_t p = s_p[j];
+				j = p >= 0 ? p >> 2 : -1;
+			}
+		}
+		__syncthreads();
+		for (int32_t k = threadIdx.x; k < nc; k += BT_BLOCK) {          // chain.c:380-392
+			const unsigned long long ky = skey[cb + k];
+			int32_t j = (int32_t)(uint32_t)ky, cnt = 1;                  // the peak is taken unconditionally (do-while)
+			{ const int32_t p = s_p[j]; j = p >= 0 ? p >> 2 : -1; }
+			while (j >= 0 && s_own[j] == k) {
+				++cnt;
+				const int32_t p = s_p[j];
+				j = p >= 0 ? p >> 2 : -1;
+			}
+			unsigned long long sc = ky >> 32;
+			bool keep = true;
+			if (j >= 0) {
+				const int32_t fj = sr[j].f;
+				keep = (int32_t)(ky >> 32) - fj >= min_sc;
+				sc = (ky >> 32) - (unsigned long long)(long long)fj;
+			}
+			keep = keep && cnt >= min_cnt;
+			ccnt[cb + k] = keep ? cnt : 0;
+			cu[cb + k] = sc << 32 | (unsigned long long)(uint32_t)cnt;
+		}
+	}
+}
+
 // B6: owner[x] = best (smallest) rank among the chains whose path contains x
 __global__ __launch_bounds__(BT_BLOCK) void k_bt_own(int64_t n_reads, const int64_t *__restrict__ soff, const SeedRec *__restrict__ s,
                                                      const int64_t *__restrict__ ends_off, const unsigned long long *__restrict__ skey,
@@ -159,6 +214,7 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_own(int64_t n_reads, const int6
 	const int64_t n_e = ends_off[n_reads];
 	for (int64_t c = (int64_t)blockIdx.x * BT_BLOCK + threadIdx.x; c < n_e; c += (int64_t)gridDim.x * BT_BLOCK) {
 		const int64_t r = bt_read_of(ends_off, 0, n_reads - 1, c);
+		if (soff[r + 1] - soff[r] <= BT_LDS_RECS) continue;         // done in LDS by k_bt_read_lds
 		const int32_t k = (int32_t)(c - ends_off[r]);
 		const SeedRec *sr = s + soff[r];
 		int32_t *ow = owner + soff[r];
@@ -180,6 +236,7 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_score(int64_t n_reads, int min_
 	const int64_t n_e = ends_off[n_reads];
 	for (int64_t c = (int64_t)blockIdx.x * BT_BLOCK + threadIdx.x; c < n_e; c += (int64_t)gridDim.x * BT_BLOCK) {
 		const int64_t r = bt_read_of(ends_off, 0, n_reads - 1, c);
+		if (soff[r + 1] - soff[r] <= BT_LDS_RECS) continue;         // done in LDS by k_bt_read_lds
 		const int32_t k = (int32_t)(c - ends_off[r]);
 		const SeedRec *sr = s + soff[r];
 		const int32_t *ow = owner + soff[r];
@@ -397,6 +454,8 @@ hipError_t launch_backtrack(hipStream_t st, int min_cnt, int min_sc, int64_t n_r
 	const unsigned gE = bt_grid(m, BT_BLOCK);                       // ends <= records
 	hipLaunchKernelGGL(k_bt_peaks, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, d_soff, s, sc.ends_off, sc.end_rec, sc.key);
 	hipLaunchKernelGGL(k_bt_rank, dim3(bt_grid(n_reads, 1)), dim3(BT_BLOCK), 0, st, n_reads, sc.ends_off, sc.key, sc.skey);
+	hipLaunchKernelGGL(k_bt_read_lds, dim3(bt_grid(n_reads, 1)), dim3(BT_BLOCK), (size_t)BT_LDS_RECS * 8, st, n_reads, min_cnt, min_sc, d_soff, s,
+	                   sc.ends_off, sc.skey, sc.ccnt, sc.cu);
 	hipLaunchKernelGGL(k_bt_own, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, d_soff, s, sc.ends_off, sc.skey, sc.owner);
 	hipLaunchKernelGGL(k_bt_score, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, min_cnt, min_sc, d_soff, s, sc.ends_off, sc.skey, sc.owner, sc.ccnt, sc.cu);
 	hipLaunchKernelGGL(k_bt_layout, dim3(bt_grid(n_reads, 4)), dim3(BT_BLOCK), 0, st, n_reads, sc.ends_off, sc.ccnt, sc.kpos, sc.bpos, sc.read_tot);
