@@ -47,6 +47,9 @@ CASES = [  # generator, generator overrides, DP preset, DP overrides, reads, per
     ("skew", dict(skew_max=30000), "ava-ont", {}, 100, False),
     ("ties", {}, "map-ont", dict(max_skip=0), 50, False),
     ("ties", {}, "map-ont", dict(max_skip=2, bw=30), 50, False),
+    ("ties", {}, "map-ont", dict(max_skip=-1), 30, False),            # ++n_skip > -1: the first marked predecessor breaks
+    ("ties", {}, "map-ont", dict(min_sc=-5, bw=0), 30, False),        # everything is "v >= min_sc"; only the exact diagonal chains
+    ("ava-ont", dict(q_span=255, span_jitter=0), "ava-ont", {}, 40, False),   # 8-bit span at its maximum
 ]
 
 
