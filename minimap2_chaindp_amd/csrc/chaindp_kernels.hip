@@ -375,6 +375,8 @@ struct Pairs {
 	int sc;          // their score incl. f[j] (chain.c:262-273); INT_MIN on the other lanes
 	int pj;          // p[j] (unit-relative) where ok
 	bool cont;       // the chunk's last lane is still inside the window and the unit: another chunk may follow
+	                 // (general/deep evaluation sets it; the fast evaluation leaves it to chunk_continues())
+	uint32_t dr;     // fast evaluation only: x_i - x_j per lane
 };
 
 // Fast variant (see k_chain_units): every difference is exact in 32 bits, same segment everywhere, cost from
@@ -401,7 +403,8 @@ __device__ __forceinline__ Pairs eval_fast(const UnitCtx &c, uint32_t xi, int qi
 	const int sc = sc0 + (int)e.z - (int)c.s_lut[di];                                    // chain.c:272-273 via the table
 	P.sc = __builtin_amdgcn_inverse_ballot_w64(P.ok) ? sc : INT_MIN;
 	P.pj = (int)e.w;
-	P.cont = (uint32_t)__builtin_amdgcn_readlane((int)dr, 63) <= maxx;
+	P.cont = false;
+	P.dr = dr;
 	return P;
 }
 
@@ -452,6 +455,7 @@ __device__ __forceinline__ Pairs eval_general(const UnitCtx &c, const ulonglong2
 	P.sc = ok ? sc : INT_MIN;
 	P.pj = pj;
 	P.cont = __builtin_amdgcn_ballot_w64(live) == ~0ull;
+	P.dr = 0;
 	return P;
 }
 
@@ -467,7 +471,24 @@ __device__ __forceinline__ uint64_t low_mask64(int n)
 // ring go to LDS.  Marks on older targets matter only if the scan later reaches a deep chunk; ring chunks do
 // not write them (replay_far_marks does, on demand); deep chunks write all of theirs to the global array.
 // Returns true when the scan for anchor i is complete (break taken, or window / unit exhausted).
-template <int RING, bool DEEP>
+// x sorted => dr grows with the lane: every lane is inside the window iff the last one is
+template <bool FASTEVAL>
+__device__ __forceinline__ bool chunk_continues(const UnitCtx &c, const Pairs &P)
+{
+	if constexpr (FASTEVAL) return (uint32_t)__builtin_amdgcn_readlane((int)P.dr, 63) <= (uint32_t)c.maxx;
+	else return P.cont;
+}
+
+// highest set bit of a 64-bit lane mask; -64 for an empty mask (s_flbit_i32_b64 returns -1), which still gives an
+// empty s_bfm_b64 mask because only the low 6 bits of the width are used
+__device__ __forceinline__ int highest_lane(uint64_t m)
+{
+	int r;
+	asm("s_flbit_i32_b64 %0, %1" : "=s"(r) : "s"(m));
+	return r ^ 63;
+}
+
+template <int RING, bool DEEP, bool FASTEVAL>
 __device__ __forceinline__ bool apply_chunk(const UnitCtx &c, const Pairs &P, int i, int kb0, int &max_f, int &max_j, int &n_skip)
 {
 	constexpr int MASK = RING - 1;
@@ -495,7 +516,7 @@ __device__ __forceinline__ bool apply_chunk(const UnitCtx &c, const Pairs &P, in
 	const uint64_t A = P.ok & __builtin_amdgcn_ballot_w64(P.sc > excl);
 	const uint64_t B = P.ok & ~A & __builtin_amdgcn_ballot_w64(tj == tag);                // chain.c:277
 	// n_skip walk (chain.c:276,278): A lanes x -> max(x-1,0), B lanes x -> x+1, break when > max_skip
-	const int hiA = 63 - __builtin_clzll(A | 1ull);                // highest A lane (0 when A is empty or {0})
+	const int hiA = highest_lane(A);                               // highest A lane (harmless -64 when A is empty)
 	if ((B & low_mask64(hiA)) == 0) {                              // every A lane precedes every B lane (or one set is empty)
 		if (A) {                                                   // the break, if any, is a B lane above every A lane: all A
 			max_f = __builtin_amdgcn_readlane(P.sc, hiA);          // lanes count, and the last one holds the running max
@@ -508,7 +529,7 @@ __device__ __forceinline__ bool apply_chunk(const UnitCtx &c, const Pairs &P, in
 		need = need < 1 ? 1 : need;
 		if (cb >= need) return true;                               // break taken (chain.c:278-279)
 		n_skip = x + cb;
-		return !P.cont;
+		return !chunk_continues<FASTEVAL>(c, P);
 	}
 	// general: clamped walk via prefix min
 	const bool isA = __builtin_amdgcn_inverse_ballot_w64(A), isB = __builtin_amdgcn_inverse_ballot_w64(B);
@@ -524,7 +545,7 @@ __device__ __forceinline__ bool apply_chunk(const UnitCtx &c, const Pairs &P, in
 	}
 	if (m) return true;
 	n_skip = __builtin_amdgcn_readlane(x, 63);
-	return !P.cont;
+	return !chunk_continues<FASTEVAL>(c, P);
 }
 
 // Before the first deep chunk of anchor i: write the marks of the ring chunks whose targets are older than the
@@ -579,11 +600,11 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 					Pairs P;
 					if constexpr (GEN) P = eval_general<RING, false>(c, an, ii, qi, span, i, kb0);
 					else P = eval_fast<RING>(c, xi, qi, span, i, kb0);
-					done = apply_chunk<RING, false>(c, P, i, kb0, max_f, max_j, n_skip);
+					done = apply_chunk<RING, false, !GEN>(c, P, i, kb0, max_f, max_j, n_skip);
 				} else {
 					if (kb0 == RING) replay_far_marks<RING, GEN>(c, an, ii, xi, qi, span, i);
 					const Pairs P = eval_general<RING, true>(c, an, ii, qi, span, i, kb0);
-					done = apply_chunk<RING, true>(c, P, i, kb0, max_f, max_j, n_skip);
+					done = apply_chunk<RING, true, false>(c, P, i, kb0, max_f, max_j, n_skip);
 				}
 				if (done) break;
 			}
