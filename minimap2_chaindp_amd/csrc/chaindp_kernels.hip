@@ -593,20 +593,30 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 			const uint32_t xi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)an.x, ii);
 			const int qi = __builtin_amdgcn_readlane((int)(uint32_t)an.y, ii);
 			const int span = span_of_hi((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(an.y >> 32), ii));
-			int max_f = span, max_j = -1, n_skip = 0;
-			for (int kb0 = 0; kb0 < i; kb0 += 64) {
-				bool done;
-				if (kb0 + 64 <= RING) {
-					Pairs P;
-					if constexpr (GEN) P = eval_general<RING, false>(c, an, ii, qi, span, i, kb0);
-					else P = eval_fast<RING>(c, xi, qi, span, i, kb0);
-					done = apply_chunk<RING, false, !GEN>(c, P, i, kb0, max_f, max_j, n_skip);
-				} else {
-					if (kb0 == RING) replay_far_marks<RING, GEN>(c, an, ii, xi, qi, span, i);
-					const Pairs P = eval_general<RING, true>(c, an, ii, qi, span, i, kb0);
-					done = apply_chunk<RING, true, false>(c, P, i, kb0, max_f, max_j, n_skip);
+			int max_f = span, max_j = -1;
+			if (i > 0) {
+				// chunk 0 (the 64 nearest predecessors) settles most anchors; further chunks are the exception
+				int n_skip = 0;
+				Pairs P0;
+				if constexpr (GEN) P0 = eval_general<RING, false>(c, an, ii, qi, span, i, 0);
+				else P0 = eval_fast<RING>(c, xi, qi, span, i, 0);
+				const bool done0 = apply_chunk<RING, false, !GEN>(c, P0, i, 0, max_f, max_j, n_skip);
+				if (__builtin_expect(!done0 && i > 64, 0)) {
+					for (int kb0 = 64; kb0 < i; kb0 += 64) {
+						bool done;
+						if (kb0 + 64 <= RING) {
+							Pairs P;
+							if constexpr (GEN) P = eval_general<RING, false>(c, an, ii, qi, span, i, kb0);
+							else P = eval_fast<RING>(c, xi, qi, span, i, kb0);
+							done = apply_chunk<RING, false, !GEN>(c, P, i, kb0, max_f, max_j, n_skip);
+						} else {
+							if (kb0 == RING) replay_far_marks<RING, GEN>(c, an, ii, xi, qi, span, i);
+							const Pairs P = eval_general<RING, true>(c, an, ii, qi, span, i, kb0);
+							done = apply_chunk<RING, true, false>(c, P, i, kb0, max_f, max_j, n_skip);
+						}
+						if (done) break;
+					}
 				}
-				if (done) break;
 			}
 			// epilogue (chain.c:283-284): anchor i enters the ring; v of the previous anchor is completed
 			const int vprev = pend_vj > pend_mf ? pend_vj : pend_mf;
