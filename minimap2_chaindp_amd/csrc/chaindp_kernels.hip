@@ -178,7 +178,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_rea
 			start = g == rs || an.x - a[g - 1].x > maxx;
 			const bool next_starts = g + 1 >= re || a[g + 1].x - an.x > maxx;
 			single = start && next_starts;
-			tg[g] = 0;
+			tg[g] = -1;
 			if (single) {                                          // chain.c:251,283-284 with an empty window
 				f[g] = span; p[g] = -1; v[g] = span;
 				flags[g] = (uint8_t)(span >= par.min_sc ? 2 : 0);  // emitted at its own step iff v >= min_sc (chain.c:304)
@@ -493,9 +493,9 @@ __device__ __forceinline__ bool apply_chunk(const UnitCtx &c, const Pairs &P, in
 {
 	constexpr int MASK = RING - 1;
 	const int lane = c.lane;
-	const int tag = i + 1;
+	const int tag = i;                                              // t[] starts at -1 (never a valid i)
 	const int j = i - 1 - kb0 - lane;
-	int tj = 0;
+	int tj = -1;
 	if constexpr (!DEEP) {
 		// lanes without a mark to make store into a dummy word instead of being masked off (no exec juggling)
 		const int lo = i - RING > 0 ? i - RING : 0;
@@ -557,7 +557,7 @@ __device__ __forceinline__ void replay_far_marks(const UnitCtx &c, const ulonglo
 		Pairs P;
 		if constexpr (GEN) P = eval_general<RING, false>(c, an, ii, qi, span, i, kb0);
 		else P = eval_fast<RING>(c, xi, qi, span, i, kb0);
-		if (__builtin_amdgcn_inverse_ballot_w64(P.ok) && P.pj >= 0 && P.pj < i - RING) c.tg[c.base + P.pj] = i + 1;
+		if (__builtin_amdgcn_inverse_ballot_w64(P.ok) && P.pj >= 0 && P.pj < i - RING) c.tg[c.base + P.pj] = i;
 	}
 }
 
@@ -594,8 +594,9 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 			const int qi = __builtin_amdgcn_readlane((int)(uint32_t)an.y, ii);
 			const int span = span_of_hi((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(an.y >> 32), ii));
 			int max_f = span, max_j = -1;
-			if (i > 0) {
-				// chunk 0 (the 64 nearest predecessors) settles most anchors; further chunks are the exception
+			{
+				// chunk 0 (the 64 nearest predecessors) settles most anchors; further chunks are the exception.  It also
+				// runs for the unit's first anchor: every lane then fails the window / range test and nothing happens.
 				int n_skip = 0;
 				Pairs P0;
 				if constexpr (GEN) P0 = eval_general<RING, false>(c, an, ii, qi, span, i, 0);
@@ -705,7 +706,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 		const bool general = par.is_cdna || n_segs > 1 || (sq & SUMQ_SEG_FLAG) || lut == nullptr || !x32_ok;
 
 		wave_mem_fence();
-		for (int k = lane; k < RING; k += 64) c.s_t[k] = 0;
+		for (int k = lane; k < RING; k += 64) c.s_t[k] = -1;
 		if (!general) {
 			const uint4 *src = (const uint4*)(lut + (int64_t)u.read * lut_stride);   // lut_stride is a multiple of 8 entries (16 B)
 			for (int k = lane; k * 8 < lut_stride; k += 64) ((uint4*)s_lut)[k] = src[k];
