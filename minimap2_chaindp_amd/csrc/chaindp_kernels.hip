@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_build_lut(Params par, int64_t n_reads, 
 		for (int dd = threadIdx.x; dd <= par.bw; dd += blockDim.x) {
 			const int lg = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
 			const int lin = (int)((double)dd * .01 * avgd);
-			lut[r * lut_stride + dd] = (uint16_t)(lin + (lg >> 1));
+			lut[r * lut_stride + dd] = (uint16_t)(int16_t)-(lin + (lg >> 1));      // stored negated: < 2^15 for bw <= 4095, q_span <= 255
 		}
 	}
 }
@@ -662,6 +662,262 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 	}
 }
 
+// ---------------------------------------------------------------- K1, fast variant
+// Ordinary reads (not cDNA, one segment, bw within the table) take this path.  It computes exactly what
+// run_unit<RING, true> computes, with the per-anchor instruction count cut to the bone (the kernel is bound by
+// VALU and SALU issue, not by memory):
+//   * LDS is addressed with raw byte addresses (the kernel has no static LDS, so the dynamic segment starts at 0;
+//     launch_chain checks that), which lets constant offsets fold into the DS instructions;
+//   * the ring entry holds x.lo, qpos, f+1 and 4*p: with x_i-1, q_i-1 and span-1 as the per-anchor scalars, the
+//     range tests "1 <= d <= max" become single unsigned compares of d-1, |dr-dq| is unchanged, and
+//     min(dq,dr,span) + f = min3(dq-1,dr-1,span-1) + (f+1); 4*p is the byte offset of the mark to write;
+//   * the three filters of chain.c:252-260 are one compare: max3(dr-1, sat(dq-1 + (max_x - max_q)),
+//     |dr-dq| + (max_x-1-bw)) < max_x (no wrap-around matters: when the first two are below max_x, so is |dr-dq|);
+//   * the cost table holds -cost as int16, so the score is one three-operand add;
+//   * prefix-max lanes without a source read 0 instead of INT_MIN: the running max is >= q_span >= 0, so a
+//     floor of 0 changes nothing and saves the copy in front of the DPP chain;
+//   * v[] (chain.c:284) is not part of the recurrence at all: v[i] = max(f[i], v[p[i]]) is computed per 64-anchor
+//     tile at flush time by pointer doubling over the tile (6 rounds of ds_bpermute), not per anchor.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x2_t __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LDS_PTR(T, a) ((__attribute__((address_space(3))) T*)(a))
+#else
+#define LDS_PTR(T, a) ((T*)(uintptr_t)(a))          /* host pass of the single-source compile; never executed */
+#endif
+__device__ __forceinline__ uint4 lds_load_b128(uint32_t a) { const u32x4_t t = *LDS_PTR(const u32x4_t, a); return make_uint4(t.x, t.y, t.z, t.w); }
+__device__ __forceinline__ int2 lds_load_b64(uint32_t a) { const i32x2_t t = *LDS_PTR(const i32x2_t, a); return make_int2(t.x, t.y); }
+__device__ __forceinline__ int lds_load_b32(uint32_t a) { return *LDS_PTR(const int, a); }
+__device__ __forceinline__ int lds_load_i16(uint32_t a) { return (int)*LDS_PTR(const short, a); }
+__device__ __forceinline__ void lds_store_b32(uint32_t a, int v) { *LDS_PTR(int, a) = v; }
+__device__ __forceinline__ void lds_store_b128(uint32_t a, uint4 v) { u32x4_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *LDS_PTR(u32x4_t, a) = t; }
+
+// inclusive prefix max of max(v, 0)-floored values (see above), then the value of lane-1 (0 for lane 0)
+__device__ __forceinline__ int wave_excl_max_floor0(int v)
+{
+	v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, true));
+	v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(2), 0xf, 0xf, true));
+	v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(4), 0xf, 0xf, true));
+	v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(8), 0xf, 0xf, true));
+	v = max(v, dpp_or_old<DPP_ROW_BCAST15, 0xa>(INT_MIN, v));
+	v = max(v, dpp_or_old<DPP_ROW_BCAST31, 0xc>(INT_MIN, v));
+	return __builtin_amdgcn_update_dpp(0, v, DPP_WAVE_SHR1, 0xf, 0xf, true);
+}
+
+template <int RING>
+struct FastLds {
+	static constexpr uint32_t RB = 16u * RING;            // ring entries
+	static constexpr uint32_t T_OFF = RB;                 // mark tags
+	static constexpr uint32_t V_OFF = RB + 4u * RING;     // v
+	static constexpr uint32_t DUMMY = 32u * RING;         // sink for lanes without a mark to write
+	static constexpr uint32_t LUT = 32u * RING + 16u;     // -cost table (int16)
+};
+
+struct FastK {
+	uint32_t L4;       // lane * 16
+	uint32_t dummy;    // DUMMY - T_OFF, kept opaque so that T_OFF stays in the DS instruction's offset field
+	uint32_t M;        // max_dist_x
+	uint32_t cbw;      // max(max_dist_x - 1 - bw, 0)
+	uint32_t dq_off;   // max_dist_x - min(max_dist_x, max_dist_y)
+	uint32_t bw;
+	int max_skip;
+};
+
+struct FastPairs { uint4 e; uint32_t drm1, dd; bool ok; };
+
+// filters of chain.c:252-260 for lane k <-> slot address (S - 16k) mod ring bytes
+template <int RING, bool SAMEGAP>
+__device__ __forceinline__ FastPairs fast_filters(const FastK &k, uint32_t addr, uint32_t xm1, uint32_t qm1)
+{
+	FastPairs P;
+	P.e = lds_load_b128(addr);
+	P.drm1 = xm1 - P.e.x;
+	const uint32_t dqm1 = qm1 - P.e.y;
+	P.dd = absdiff_u32(P.drm1, dqm1);
+	const uint32_t dqs = SAMEGAP ? dqm1 : __builtin_elementwise_add_sat(dqm1, k.dq_off);
+	const uint32_t m2 = P.drm1 > dqs ? P.drm1 : dqs, t = P.dd + k.cbw;
+	P.ok = (m2 > t ? m2 : t) < k.M;
+	P.e.y = dqm1;
+	return P;
+}
+
+// One chunk of 64 ring predecessors of anchor i (lane k <-> j = jtop - k, S = 16 * jtop): evaluation plus the
+// serial semantics of chain.c:274-281.  Returns true when the scan for anchor i is complete.
+template <int RING, bool SAMEGAP>
+__device__ __forceinline__ bool fast_chunk(const FastK &k, uint32_t S, int jtop, uint32_t xm1, uint32_t qm1, int spm1,
+                                           int i, int lo4, int &max_f, int &max_j, int &n_skip)
+{
+	typedef FastLds<RING> L;
+	const uint32_t addr = (S - k.L4) & (L::RB - 1u);
+	const FastPairs P = fast_filters<RING, SAMEGAP>(k, addr, xm1, qm1);
+	const int dqm1 = (int)P.e.y, drm1 = (int)P.drm1;
+	int sc0 = dqm1 < drm1 ? dqm1 : drm1;
+	sc0 = sc0 < spm1 ? sc0 : spm1;                                                      // chain.c:262-263, minus one
+	const uint32_t di = P.dd < k.bw ? P.dd : k.bw;
+	const int scu = sc0 + (int)P.e.z + lds_load_i16(L::LUT + 2u * di);                  // chain.c:272-273 via the table
+	const int sc = P.ok ? scu : INT_MIN;
+	// marks (chain.c:281): lanes without one store into the dummy word instead of being masked off
+	const bool near = P.ok && (int)P.e.w >= lo4;
+	const uint32_t dst = near ? (P.e.w & (4u * RING - 1u)) : k.dummy;
+	lds_store_b32(dst + L::T_OFF, i);
+	wave_mem_fence();
+	const int tj = lds_load_b32((addr >> 2) + L::T_OFF);
+	int excl = wave_excl_max_floor0(sc);
+	excl = excl > max_f ? excl : max_f;
+	const uint64_t A = __builtin_amdgcn_ballot_w64(sc > excl);                          // chain.c:274 (masked lanes hold INT_MIN)
+	const uint64_t B = __builtin_amdgcn_ballot_w64(P.ok) & ~A & __builtin_amdgcn_ballot_w64(tj == i);   // chain.c:277
+	const int hiA = highest_lane(A);
+	if ((B & low_mask64(hiA)) == 0) {                              // every A lane precedes every B lane (or one set is empty)
+		if (A) {
+			max_f = __builtin_amdgcn_readlane(sc, hiA);
+			max_j = jtop - hiA;
+		}
+		int x = n_skip - __builtin_popcountll(A);
+		x = x < 0 ? 0 : x;
+		const int cb = __builtin_popcountll(B);
+		int need = k.max_skip - x + 1;
+		need = need < 1 ? 1 : need;
+		if (cb >= need) return true;                               // break taken (chain.c:278-279)
+		n_skip = x + cb;
+	} else {                                                       // general: clamped walk via prefix min
+		const bool isA = __builtin_amdgcn_inverse_ballot_w64(A), isB = __builtin_amdgcn_inverse_ballot_w64(B);
+		const int Sk = n_skip + lanes_below(B) + (int)isB - lanes_below(A) - (int)isA;
+		const int Mk = wave_scan_min(Sk);
+		const int x = Sk - (Mk < 0 ? Mk : 0);
+		const uint64_t m = B & __builtin_amdgcn_ballot_w64(x > k.max_skip);
+		const uint64_t Ap = m ? (A & ((1ull << __builtin_ctzll(m)) - 1)) : A;   // A lanes before the break
+		if (Ap) {
+			const int ka = 63 - __builtin_clzll(Ap);
+			max_f = __builtin_amdgcn_readlane(sc, ka);
+			max_j = jtop - ka;
+		}
+		if (m) return true;
+		n_skip = __builtin_amdgcn_readlane(x, 63);
+	}
+	// x sorted => dr grows with the lane: another chunk can only matter if the last lane is inside the window
+	return (uint32_t)__builtin_amdgcn_readlane((int)P.drm1, 63) + 1u > k.M;
+}
+
+template <int RING, bool SAMEGAP>
+__device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
+{
+	typedef FastLds<RING> L;
+	constexpr int MASK = RING - 1;
+	const int lane = c.lane;
+	FastK k;
+	k.L4 = (uint32_t)lane << 4;
+	k.dummy = L::DUMMY - L::T_OFF;
+	asm volatile("" : "+v"(k.L4), "+v"(k.dummy));           // opaque: keeps (S - 16*lane) & mask at two instructions
+	k.M = (uint32_t)c.maxx;
+	k.bw = (uint32_t)c.bw;
+	k.cbw = k.M - 1u > k.bw ? k.M - 1u - k.bw : 0u;
+	k.dq_off = k.M - (uint32_t)c.mdq;
+	k.max_skip = c.max_skip;
+	uint64_t x_carry = 0;
+	for (int tile0 = 0;; tile0 += 64) {
+		const int64_t gi = c.base + tile0 + lane;
+		const bool have = tile0 + lane < room;
+		ulonglong2 an = make_ulonglong2(0, 0);
+		if (have) an = c.a[gi];
+		uint64_t xp;
+		{
+			const uint32_t lo = (uint32_t)wave_shift_up1((int)(uint32_t)an.x, (int)(uint32_t)x_carry);
+			const uint32_t hi = (uint32_t)wave_shift_up1((int)(uint32_t)(an.x >> 32), (int)(uint32_t)(x_carry >> 32));
+			xp = (uint64_t)hi << 32 | lo;
+		}
+		const bool stop = !have || ((tile0 + lane) > 0 && an.x - xp > c.maxx);
+		const uint64_t stop_m = __builtin_amdgcn_ballot_w64(stop);
+		const int cnt = stop_m ? __builtin_ctzll(stop_m) : 64;
+		if (cnt == 0) break;
+		x_carry = readlane_u64(an.x, 63);
+
+		const uint32_t xm1v = (uint32_t)an.x - 1u, qm1v = (uint32_t)an.y - 1u;
+		const int spm1v = span_of_hi((uint32_t)(an.y >> 32)) - 1;
+		const uint32_t waddr = (uint32_t)((tile0 + lane) & MASK) << 4;
+		uint4 W;
+		W.x = (uint32_t)an.x; W.y = (uint32_t)an.y;
+		for (int ii = 0; ii < cnt; ++ii) {
+			const int i = tile0 + ii;                          // unit-relative index of the anchor being scored
+			const uint32_t xm1 = (uint32_t)__builtin_amdgcn_readlane((int)xm1v, ii);
+			const uint32_t qm1 = (uint32_t)__builtin_amdgcn_readlane((int)qm1v, ii);
+			const int spm1 = __builtin_amdgcn_readlane(spm1v, ii);
+			const int lo4 = i > RING ? (i - RING) << 2 : 0;
+			int max_f = spm1 + 1, max_j = -1, n_skip = 0;
+			// chunk 0 (the 64 nearest predecessors) settles most anchors.  It also runs for the unit's first anchors:
+			// slots not written yet fail the window test, so nothing happens on those lanes.
+			const bool done0 = fast_chunk<RING, SAMEGAP>(k, (uint32_t)(i - 1) << 4, i - 1, xm1, qm1, spm1, i, lo4, max_f, max_j, n_skip);
+			if (!done0) {
+				for (int kb0 = 64; kb0 < i; kb0 += 64) {
+					bool done;
+					if (kb0 + 64 <= RING) {
+						done = fast_chunk<RING, SAMEGAP>(k, (uint32_t)(i - 1 - kb0) << 4, i - 1 - kb0, xm1, qm1, spm1, i, lo4, max_f, max_j, n_skip);
+					} else {
+						if (kb0 == RING) {
+							// first deep chunk: marks of the ring chunks whose targets are older than the ring go to the global array now
+							for (int kr = 0; kr < RING; kr += 64) {
+								const FastPairs P = fast_filters<RING, SAMEGAP>(k, ((uint32_t)((i - 1 - kr) << 4) - k.L4) & (L::RB - 1u), xm1, qm1);
+								const int pj4 = (int)P.e.w;
+								if (P.ok && pj4 >= 0 && pj4 < lo4) c.tg[c.base + (pj4 >> 2)] = i;
+							}
+						}
+						const Pairs P = eval_general<RING, true>(c, an, ii, (int)(qm1 + 1u), spm1 + 1, i, kb0);
+						done = apply_chunk<RING, true, false>(c, P, i, kb0, max_f, max_j, n_skip);
+					}
+					if (done) break;
+				}
+			}
+			// anchor i enters the ring (chain.c:283)
+			W.z = (uint32_t)(max_f + 1); W.w = (uint32_t)(max_j << 2);
+			wave_mem_fence();
+			if (lane == ii) lds_store_b128(waddr, W);
+			wave_mem_fence();
+		}
+		// tile flush: v (chain.c:284) by pointer doubling, then f/p/v and the compaction helpers
+		{
+			int fi = 0, pi = -1, val = 0, ptr = -1;
+			if (lane < cnt) {
+				const int2 zw = lds_load_b64(waddr + 8u);
+				fi = zw.x - 1; pi = zw.y >> 2;
+				val = fi; ptr = pi;
+			}
+			const bool ext = ptr >= 0 && ptr < tile0;               // predecessor in an earlier tile: its v is final
+			const bool ext_far = ext && tile0 - ptr > RING;          // ... and no longer in the LDS copy
+			if (__builtin_amdgcn_ballot_w64(ext_far)) wave_global_fence();
+			if (ext) {
+				const int vext = ext_far ? c.v[c.base + ptr] : lds_load_b32(L::V_OFF + ((uint32_t)(ptr & MASK) << 2));
+				val = vext > val ? vext : val;
+				ptr = -1;
+			}
+			for (int r = 0; r < 6; ++r) {
+				const int src = (ptr >= tile0 ? ptr - tile0 : lane) << 2;
+				const int pv = __builtin_amdgcn_ds_bpermute(src, val);
+				const int pp = __builtin_amdgcn_ds_bpermute(src, ptr);
+				if (ptr >= tile0) { val = pv > val ? pv : val; ptr = pp; }
+			}
+			wave_mem_fence();
+			if (lane < cnt) lds_store_b32(L::V_OFF + (waddr >> 2), val);
+			wave_mem_fence();
+			if (lane < cnt) {
+				c.f[gi] = fi;
+				c.p[gi] = pi < 0 ? -1 : pi + c.rel0;
+				c.v[gi] = val;
+				// Compaction (chain.c:286-317) needs, for every anchor that is not emitted at its own step, its
+				// first child; while f/p/v of the tile are at hand, record "emitted at own step" and feed that min.
+				if (pi >= 0) {
+					int vq, pq;
+					if (tile0 + cnt - 1 - pi < RING) {
+						vq = lds_load_b32(L::V_OFF + ((uint32_t)(pi & MASK) << 2));
+						pq = lds_load_b32(((uint32_t)(pi & MASK) << 4) + 12u);
+					} else { vq = c.v[c.base + pi]; pq = c.p[c.base + pi]; }
+					if (!(vq >= c.min_sc || pq >= 0)) atomicMin(&c.first_child[c.base + pi], c.rel0 + tile0 + lane);
+				}
+				c.flags[gi] = (uint8_t)((val >= c.min_sc || pi >= 0) ? 2 : 0);
+			}
+		}
+		if (cnt < 64) break;
+	}
+}
+
 template <int RING>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_chain_units(Params par, const int64_t *__restrict__ off,
                                                     const ulonglong2 *__restrict__ a, const int32_t *__restrict__ n_segs_pr,
@@ -703,7 +959,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 		c.rel0 = (int)(u.start - rs);
 		c.avgd = (double)((float)(uint64_t)(sq & ~SUMQ_SEG_FLAG) / (float)(int64_t)(re - rs));   // chain.c:241: f32 divide of converted u64 and i64
 		c.seg_rule = n_segs > 1 && !par.is_cdna;                   // chain.c:261
-		const bool general = par.is_cdna || n_segs > 1 || (sq & SUMQ_SEG_FLAG) || lut == nullptr || !x32_ok;
+		const bool general = par.is_cdna || n_segs > 1 || (sq & SUMQ_SEG_FLAG) || lut == nullptr || !x32_ok
+		                     || par.max_dist_x < 1 || par.max_dist_y < 0;
 
 		wave_mem_fence();
 		for (int k = lane; k < RING; k += 64) c.s_t[k] = -1;
@@ -711,12 +968,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 			const uint4 *src = (const uint4*)(lut + (int64_t)u.read * lut_stride);   // lut_stride is a multiple of 8 entries (16 B)
 			for (int k = lane; k * 8 < lut_stride; k += 64) ((uint4*)s_lut)[k] = src[k];
 			const uint32_t x_none = (uint32_t)a[u.start].x - (uint32_t)c.maxx - 2u;  // "no anchor here yet": fails the window test
-			for (int k = lane; k < RING; k += 64) *(uint4*)(c.s_w + 4 * k) = make_uint4(x_none, 0u, 0u, 0xffffffffu);
+			for (int k = lane; k < RING; k += 64) *(uint4*)(c.s_w + 4 * k) = make_uint4(x_none, 0u, 0u, 0xfffffffcu);
 		}
 		wave_mem_fence();
 		// u.len bounds the unit (next unit's start or the read's end); run_unit finds the true end at the first gap
 		if (general) run_unit<RING, true>(c, (int64_t)u.len);
-		else run_unit<RING, false>(c, (int64_t)u.len);
+		else if (par.max_dist_y >= par.max_dist_x) run_unit_fast<RING, true>(c, (int64_t)u.len);
+		else run_unit_fast<RING, false>(c, (int64_t)u.len);
 	}
 }
 
@@ -779,6 +1037,15 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
 	if (blocks > cap) blocks = cap;
 	const ulonglong2 *aa = (const ulonglong2*)d_a;
 	const size_t lds = chain_lds_bytes(ring, d_lut ? lut_stride : 0);
+	{
+		// the fast variant addresses LDS by raw byte offsets from 0: the kernel must have no static LDS in front of
+		// its dynamic segment
+		hipFuncAttributes fa;
+		const void *fn = ring == 128 ? (const void*)k_chain_units<128> : ring == 512 ? (const void*)k_chain_units<512> : (const void*)k_chain_units<256>;
+		const hipError_t e = hipFuncGetAttributes(&fa, fn);
+		if (e != hipSuccess) return e;
+		if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
+	}
 	switch (ring) {
 	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, d_first_child, d_flags); break;
 	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, d_first_child, d_flags); break;
