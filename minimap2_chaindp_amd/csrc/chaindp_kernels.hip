@@ -721,6 +721,7 @@ struct FastK {
 	uint32_t dq_off;   // max_dist_x - min(max_dist_x, max_dist_y)
 	uint32_t bw;
 	int max_skip;
+	int ms0;           // max(max_skip, 0): with n_skip starting at 0 the break needs more than this many B lanes
 };
 
 struct FastPairs { uint4 e; uint32_t drm1, dd; bool ok; };
@@ -741,11 +742,12 @@ __device__ __forceinline__ FastPairs fast_filters(const FastK &k, uint32_t addr,
 	return P;
 }
 
-// One chunk of 64 ring predecessors of anchor i (lane k <-> j = jtop - k, S = 16 * jtop): evaluation plus the
-// serial semantics of chain.c:274-281.  Returns true when the scan for anchor i is complete.
+// One chunk of 64 ring predecessors of anchor i (lane k <-> j = jtop - k, S = 16 * jtop): scores, marks, and the
+// lane masks A ("new running max", chain.c:274) and B ("marked and not better", chain.c:277).  Straight-line code.
+struct FastMasks { uint64_t A, B; int sc; uint32_t drm1; };
+
 template <int RING, bool SAMEGAP>
-__device__ __forceinline__ bool fast_chunk(const FastK &k, uint32_t S, int jtop, uint32_t xm1, uint32_t qm1, int spm1,
-                                           int i, int lo4, int &max_f, int &max_j, int &n_skip)
+__device__ __forceinline__ FastMasks fast_masks(const FastK &k, uint32_t S, uint32_t xm1, uint32_t qm1, int spm1, int i, int lo4, int max_f)
 {
 	typedef FastLds<RING> L;
 	const uint32_t addr = (S - k.L4) & (L::RB - 1u);
@@ -755,47 +757,87 @@ __device__ __forceinline__ bool fast_chunk(const FastK &k, uint32_t S, int jtop,
 	sc0 = sc0 < spm1 ? sc0 : spm1;                                                      // chain.c:262-263, minus one
 	const uint32_t di = P.dd < k.bw ? P.dd : k.bw;
 	const int scu = sc0 + (int)P.e.z + lds_load_i16(L::LUT + 2u * di);                  // chain.c:272-273 via the table
-	const int sc = P.ok ? scu : INT_MIN;
+	FastMasks m;
+	m.sc = P.ok ? scu : INT_MIN;
+	m.drm1 = P.drm1;
 	// marks (chain.c:281): lanes without one store into the dummy word instead of being masked off
 	const bool near = P.ok && (int)P.e.w >= lo4;
 	const uint32_t dst = near ? (P.e.w & (4u * RING - 1u)) : k.dummy;
 	lds_store_b32(dst + L::T_OFF, i);
 	wave_mem_fence();
 	const int tj = lds_load_b32((addr >> 2) + L::T_OFF);
-	int excl = wave_excl_max_floor0(sc);
+	int excl = wave_excl_max_floor0(m.sc);
 	excl = excl > max_f ? excl : max_f;
-	const uint64_t A = __builtin_amdgcn_ballot_w64(sc > excl);                          // chain.c:274 (masked lanes hold INT_MIN)
-	const uint64_t B = __builtin_amdgcn_ballot_w64(P.ok) & ~A & __builtin_amdgcn_ballot_w64(tj == i);   // chain.c:277
-	const int hiA = highest_lane(A);
-	if ((B & low_mask64(hiA)) == 0) {                              // every A lane precedes every B lane (or one set is empty)
-		if (A) {
-			max_f = __builtin_amdgcn_readlane(sc, hiA);
+	m.A = __builtin_amdgcn_ballot_w64(m.sc > excl);                                     // masked lanes hold INT_MIN
+	m.B = __builtin_amdgcn_ballot_w64(P.ok) & ~m.A & __builtin_amdgcn_ballot_w64(tj == i);
+	return m;
+}
+
+// n_skip walk when A and B lanes interleave (chain.c:276,278): A lanes x -> max(x-1,0), B lanes x -> x+1, break
+// when x > max_skip; done with a prefix min over the unclamped walk.  Returns true when the break is taken.
+__device__ __forceinline__ bool fast_walk_general(const FastK &k, const FastMasks &m, int jtop, int &max_f, int &max_j, int &n_skip)
+{
+	const bool isA = __builtin_amdgcn_inverse_ballot_w64(m.A), isB = __builtin_amdgcn_inverse_ballot_w64(m.B);
+	const int Sk = n_skip + lanes_below(m.B) + (int)isB - lanes_below(m.A) - (int)isA;
+	const int Mk = wave_scan_min(Sk);
+	const int x = Sk - (Mk < 0 ? Mk : 0);
+	const uint64_t brk = m.B & __builtin_amdgcn_ballot_w64(x > k.max_skip);
+	const uint64_t Ap = brk ? (m.A & ((1ull << __builtin_ctzll(brk)) - 1)) : m.A;      // A lanes before the break
+	if (Ap) {
+		const int ka = 63 - __builtin_clzll(Ap);
+		max_f = __builtin_amdgcn_readlane(m.sc, ka);
+		max_j = jtop - ka;
+	}
+	n_skip = __builtin_amdgcn_readlane(x, 63);
+	return brk != 0;
+}
+
+// a further ring chunk (kb0 >= 64); returns true when the scan for anchor i is complete
+template <int RING, bool SAMEGAP>
+__device__ __forceinline__ bool fast_chunk(const FastK &k, uint32_t S, int jtop, uint32_t xm1, uint32_t qm1, int spm1,
+                                           int i, int lo4, int &max_f, int &max_j, int &n_skip)
+{
+	const FastMasks m = fast_masks<RING, SAMEGAP>(k, S, xm1, qm1, spm1, i, lo4, max_f);
+	const int hiA = highest_lane(m.A);
+	if ((m.B & low_mask64(hiA)) == 0) {                            // every A lane precedes every B lane (or one set is empty)
+		if (hiA >= 0) {
+			max_f = __builtin_amdgcn_readlane(m.sc, hiA);
 			max_j = jtop - hiA;
 		}
-		int x = n_skip - __builtin_popcountll(A);
+		int x = n_skip - __builtin_popcountll(m.A);
 		x = x < 0 ? 0 : x;
-		const int cb = __builtin_popcountll(B);
-		int need = k.max_skip - x + 1;
-		need = need < 1 ? 1 : need;
-		if (cb >= need) return true;                               // break taken (chain.c:278-279)
+		const int cb = __builtin_popcountll(m.B);
 		n_skip = x + cb;
-	} else {                                                       // general: clamped walk via prefix min
-		const bool isA = __builtin_amdgcn_inverse_ballot_w64(A), isB = __builtin_amdgcn_inverse_ballot_w64(B);
-		const int Sk = n_skip + lanes_below(B) + (int)isB - lanes_below(A) - (int)isA;
-		const int Mk = wave_scan_min(Sk);
-		const int x = Sk - (Mk < 0 ? Mk : 0);
-		const uint64_t m = B & __builtin_amdgcn_ballot_w64(x > k.max_skip);
-		const uint64_t Ap = m ? (A & ((1ull << __builtin_ctzll(m)) - 1)) : A;   // A lanes before the break
-		if (Ap) {
-			const int ka = 63 - __builtin_clzll(Ap);
-			max_f = __builtin_amdgcn_readlane(sc, ka);
-			max_j = jtop - ka;
-		}
-		if (m) return true;
-		n_skip = __builtin_amdgcn_readlane(x, 63);
-	}
+		if (cb > 0 && n_skip > k.max_skip) return true;            // break taken at a B lane (chain.c:278-279); n_skip is dead then
+	} else if (fast_walk_general(k, m, jtop, max_f, max_j, n_skip)) return true;
 	// x sorted => dr grows with the lane: another chunk can only matter if the last lane is inside the window
-	return (uint32_t)__builtin_amdgcn_readlane((int)P.drm1, 63) + 1u > k.M;
+	return (uint32_t)__builtin_amdgcn_readlane((int)m.drm1, 63) + 1u > k.M;
+}
+
+// chunks beyond the first for anchor i: ring chunks, then the deep path (predecessors older than the ring, from HBM/L2)
+template <int RING, bool SAMEGAP>
+__device__ __forceinline__ void fast_more_chunks(const UnitCtx &c, const FastK &k, const ulonglong2 &an, int ii, int i, uint32_t xm1, uint32_t qm1,
+                                                 int spm1, int lo4, int &max_f, int &max_j, int &n_skip)
+{
+	typedef FastLds<RING> L;
+	for (int kb0 = 64; kb0 < i; kb0 += 64) {
+		bool done;
+		if (kb0 + 64 <= RING) {
+			done = fast_chunk<RING, SAMEGAP>(k, (uint32_t)(i - 1 - kb0) << 4, i - 1 - kb0, xm1, qm1, spm1, i, lo4, max_f, max_j, n_skip);
+		} else {
+			if (kb0 == RING) {
+				// first deep chunk: marks of the ring chunks whose targets are older than the ring go to the global array now
+				for (int kr = 0; kr < RING; kr += 64) {
+					const FastPairs P = fast_filters<RING, SAMEGAP>(k, ((uint32_t)((i - 1 - kr) << 4) - k.L4) & (L::RB - 1u), xm1, qm1);
+					const int pj4 = (int)P.e.w;
+					if (P.ok && pj4 >= 0 && pj4 < lo4) c.tg[c.base + (pj4 >> 2)] = i;
+				}
+			}
+			const Pairs P = eval_general<RING, true>(c, an, ii, (int)(qm1 + 1u), spm1 + 1, i, kb0);
+			done = apply_chunk<RING, true, false>(c, P, i, kb0, max_f, max_j, n_skip);
+		}
+		if (done) break;
+	}
 }
 
 template <int RING, bool SAMEGAP>
@@ -813,6 +855,7 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 	k.cbw = k.M - 1u > k.bw ? k.M - 1u - k.bw : 0u;
 	k.dq_off = k.M - (uint32_t)c.mdq;
 	k.max_skip = c.max_skip;
+	k.ms0 = c.max_skip > 0 ? c.max_skip : 0;
 	uint64_t x_carry = 0;
 	for (int tile0 = 0;; tile0 += 64) {
 		const int64_t gi = c.base + tile0 + lane;
@@ -841,35 +884,41 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 			const uint32_t xm1 = (uint32_t)__builtin_amdgcn_readlane((int)xm1v, ii);
 			const uint32_t qm1 = (uint32_t)__builtin_amdgcn_readlane((int)qm1v, ii);
 			const int spm1 = __builtin_amdgcn_readlane(spm1v, ii);
-			const int lo4 = i > RING ? (i - RING) << 2 : 0;
+			const int lo4 = max((i - RING) << 2, 0);           // byte offset of the oldest mark slot still in the ring
 			int max_f = spm1 + 1, max_j = -1, n_skip = 0;
 			// chunk 0 (the 64 nearest predecessors) settles most anchors.  It also runs for the unit's first anchors:
-			// slots not written yet fail the window test, so nothing happens on those lanes.
-			const bool done0 = fast_chunk<RING, SAMEGAP>(k, (uint32_t)(i - 1) << 4, i - 1, xm1, qm1, spm1, i, lo4, max_f, max_j, n_skip);
-			if (!done0) {
-				for (int kb0 = 64; kb0 < i; kb0 += 64) {
-					bool done;
-					if (kb0 + 64 <= RING) {
-						done = fast_chunk<RING, SAMEGAP>(k, (uint32_t)(i - 1 - kb0) << 4, i - 1 - kb0, xm1, qm1, spm1, i, lo4, max_f, max_j, n_skip);
-					} else {
-						if (kb0 == RING) {
-							// first deep chunk: marks of the ring chunks whose targets are older than the ring go to the global array now
-							for (int kr = 0; kr < RING; kr += 64) {
-								const FastPairs P = fast_filters<RING, SAMEGAP>(k, ((uint32_t)((i - 1 - kr) << 4) - k.L4) & (L::RB - 1u), xm1, qm1);
-								const int pj4 = (int)P.e.w;
-								if (P.ok && pj4 >= 0 && pj4 < lo4) c.tg[c.base + (pj4 >> 2)] = i;
-							}
-						}
-						const Pairs P = eval_general<RING, true>(c, an, ii, (int)(qm1 + 1u), spm1 + 1, i, kb0);
-						done = apply_chunk<RING, true, false>(c, P, i, kb0, max_f, max_j, n_skip);
+			// slots not written yet fail the window test, so nothing happens on those lanes.  Written out with
+			// explicit exits so that the common path (break inside chunk 0) is straight-line scalar code.
+			{
+				const FastMasks m = fast_masks<RING, SAMEGAP>(k, (uint32_t)(i - 1) << 4, xm1, qm1, spm1, i, lo4, max_f);
+				const int hiA = highest_lane(m.A);
+				if ((m.B & low_mask64(hiA)) == 0) {                    // every A lane precedes every B lane (or one set is empty)
+					if (hiA >= 0) {
+						max_f = __builtin_amdgcn_readlane(m.sc, hiA);
+						max_j = i - 1 - hiA;
 					}
-					if (done) break;
+					n_skip = __builtin_popcountll(m.B);                // n_skip was 0: A lanes cannot lower it
+					if (n_skip > k.ms0) goto anchor_done;              // break taken at a B lane (chain.c:278-279)
+					if ((uint32_t)__builtin_amdgcn_readlane((int)m.drm1, 63) + 1u > k.M) goto anchor_done;   // window exhausted
+					fast_more_chunks<RING, SAMEGAP>(c, k, an, ii, i, xm1, qm1, spm1, lo4, max_f, max_j, n_skip);
+				} else {
+					// A and B lanes interleave (rare): own copy of the tail, so that the common path above shares no
+					// control flow (and no merged exit flags) with it
+					if (fast_walk_general(k, m, i - 1, max_f, max_j, n_skip)) goto anchor_done;
+					if ((uint32_t)__builtin_amdgcn_readlane((int)m.drm1, 63) + 1u > k.M) goto anchor_done;
+					fast_more_chunks<RING, SAMEGAP>(c, k, an, ii, i, xm1, qm1, spm1, lo4, max_f, max_j, n_skip);
 				}
 			}
+		anchor_done:
 			// anchor i enters the ring (chain.c:283)
 			W.z = (uint32_t)(max_f + 1); W.w = (uint32_t)(max_j << 2);
 			wave_mem_fence();
-			if (lane == ii) lds_store_b128(waddr, W);
+			{
+				// single-lane store with the exec mask set by hand: no branch in the IR, so the anchor loop has only
+				// wave-uniform control flow (exec is all ones here: 64-thread workgroups, uniform branches only)
+				u32x4_t w4; w4.x = W.x; w4.y = W.y; w4.z = W.z; w4.w = W.w;
+				asm volatile("s_bfm_b64 exec, 1, %0\n\tds_write_b128 %1, %2\n\ts_mov_b64 exec, -1" :: "s"(ii), "v"(waddr), "v"(w4) : "memory");
+			}
 			wave_mem_fence();
 		}
 		// tile flush: v (chain.c:284) by pointer doubling, then f/p/v and the compaction helpers
