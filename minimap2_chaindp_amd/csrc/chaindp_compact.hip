@@ -25,7 +25,7 @@ namespace chaindp {
 struct SeedRec { uint64_t x, y; int32_t p, f; };   // == struct new_seed (minimap.h:51-55)
 
 #define CMP_BLOCK 256
-#define CMP_PER_BLOCK 1024
+#define CMP_PER_BLOCK CHAINDP_BLOCK_ANCHORS
 
 __device__ __forceinline__ bool self_emit(int32_t vi, int32_t pi, int min_sc) { return vi >= min_sc || pi >= 0; }
 
@@ -39,17 +39,11 @@ __device__ __forceinline__ int64_t read_of_c(const int64_t *__restrict__ off, in
 	return lo;
 }
 
-// reads touched by a block's anchor range, found once per block
-__device__ __forceinline__ void block_read_range(const int64_t *__restrict__ off, int64_t n_reads, int64_t g0, int64_t g1,
-                                                 int64_t &rlo, int64_t &rhi)
+// reads touched by a block's anchor range: tabulated by the prepass (k_block_reads), same 1024-anchor blocks
+__device__ __forceinline__ void block_read_range(const int2 *__restrict__ block_reads, int64_t &rlo, int64_t &rhi)
 {
-	__shared__ int64_t s_r[2];
-	if (threadIdx.x == 0) {
-		s_r[0] = read_of_c(off, 0, n_reads - 1, g0);
-		s_r[1] = read_of_c(off, 0, n_reads - 1, g1 - 1);
-	}
-	__syncthreads();
-	rlo = s_r[0]; rhi = s_r[1];
+	const int2 rr = block_reads[blockIdx.x];
+	rlo = rr.x; rhi = rr.y;
 }
 
 // ---------------------------------------------------------------- exclusive scan of uint64 items (3 small kernels)
@@ -122,14 +116,16 @@ hipError_t launch_scan_u64(hipStream_t st, int64_t n, unsigned long long *d_data
 __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t total,
                                                      const int64_t *__restrict__ off, const int32_t *__restrict__ p,
                                                      const int32_t *__restrict__ first_child,
-                                                     uint8_t *__restrict__ flags, unsigned long long *__restrict__ block_cnt)
+                                                     uint8_t *__restrict__ flags, unsigned long long *__restrict__ block_cnt,
+                                                     const int2 *__restrict__ block_reads)
 {
 	__shared__ unsigned int s_cnt;
 	const int64_t g0 = (int64_t)blockIdx.x * CMP_PER_BLOCK;
 	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
 	int64_t rlo, rhi;
 	if (threadIdx.x == 0) s_cnt = 0;
-	block_read_range(off, n_reads, g0, g1, rlo, rhi);
+	__syncthreads();
+	block_read_range(block_reads, rlo, rhi);
 	unsigned int mine = 0;
 	for (int64_t g = g0 + threadIdx.x; g < g1; g += CMP_BLOCK) {
 		const int32_t q = p[g];
@@ -153,14 +149,15 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t to
 __global__ __launch_bounds__(CMP_BLOCK) void k_positions(int64_t n_reads, int64_t total, const int64_t *__restrict__ off,
                                                          const int32_t *__restrict__ p, const uint8_t *__restrict__ flags,
                                                          const unsigned long long *__restrict__ block_base,
-                                                         int32_t *__restrict__ id, int64_t *__restrict__ seeds_off)
+                                                         int32_t *__restrict__ id, int64_t *__restrict__ seeds_off,
+                                                         const int2 *__restrict__ block_reads)
 {
 	__shared__ unsigned int s_w[4];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int64_t g0 = (int64_t)blockIdx.x * CMP_PER_BLOCK;
 	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
 	int64_t rlo, rhi;
-	block_read_range(off, n_reads, g0, g1, rlo, rhi);
+	block_read_range(block_reads, rlo, rhi);
 	unsigned int carry = (unsigned int)block_base[blockIdx.x];
 	for (int64_t gb = g0; gb < g1; gb += CMP_BLOCK) {
 		const int64_t g = gb + threadIdx.x;
@@ -201,12 +198,12 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_write_seeds(Params par, int64_t n
                                                            const int32_t *__restrict__ f, const int32_t *__restrict__ p,
                                                            const int32_t *__restrict__ v, const uint8_t *__restrict__ flags,
                                                            const int32_t *__restrict__ id, const int64_t *__restrict__ seeds_off,
-                                                           SeedRec *__restrict__ seeds)
+                                                           SeedRec *__restrict__ seeds, const int2 *__restrict__ block_reads)
 {
 	const int64_t g0 = (int64_t)blockIdx.x * CMP_PER_BLOCK;
 	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
 	int64_t rlo, rhi;
-	block_read_range(off, n_reads, g0, g1, rlo, rhi);
+	block_read_range(block_reads, rlo, rhi);
 	const int min_sc = par.min_sc;
 	for (int64_t g = g0 + threadIdx.x; g < g1; g += CMP_BLOCK) {
 		const int fl = flags[g];
@@ -252,12 +249,12 @@ hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, in
 	if (total <= 0) return hipMemsetAsync(d_seeds_off, 0, (size_t)(n_reads + 1) * sizeof(int64_t), st);
 	const int64_t blocks = (total + CMP_PER_BLOCK - 1) / CMP_PER_BLOCK;
 	const dim3 g((unsigned)blocks), b(CMP_BLOCK);
-	hipLaunchKernelGGL(k_count, g, b, 0, st, n_reads, total, d_off, d_p, d_first_child, sc.flags, sc.block_cnt);
+	hipLaunchKernelGGL(k_count, g, b, 0, st, n_reads, total, d_off, d_p, d_first_child, sc.flags, sc.block_cnt, sc.block_reads);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, sc.n_seeds)) != hipSuccess) return e;
-	hipLaunchKernelGGL(k_positions, g, b, 0, st, n_reads, total, d_off, d_p, sc.flags, sc.block_cnt, d_id, d_seeds_off);
+	hipLaunchKernelGGL(k_positions, g, b, 0, st, n_reads, total, d_off, d_p, sc.flags, sc.block_cnt, d_id, d_seeds_off, sc.block_reads);
 	hipLaunchKernelGGL(k_finish_offsets, dim3(1), dim3(1), 0, st, n_reads, total, d_off, sc.n_seeds, d_seeds_off);
 	hipLaunchKernelGGL(k_write_seeds, g, b, 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a, d_f, d_p, d_v, sc.flags, d_id,
-	                   d_seeds_off, (SeedRec*)d_seeds);
+	                   d_seeds_off, (SeedRec*)d_seeds, sc.block_reads);
 	return hipGetLastError();
 }
 

@@ -19,6 +19,9 @@ struct Unit {
 	int32_t len;     // upper bound of its length (next unit's start or end of the read)
 };
 
+// the anchor-parallel kernels of the prepass and of the compaction cut the batch into blocks of this many anchors
+#define CHAINDP_BLOCK_ANCHORS 1024
+
 // prepass scratch: one 64-bit unit-start mask per 64 anchors, per-block unit / singleton counts
 struct PrepassScratch {
 	uint64_t *start_mask;
@@ -26,6 +29,7 @@ struct PrepassScratch {
 	unsigned long long *tile_tmp;    // scratch of the scan
 	Unit *units_tmp;                 // units in anchor order, before the longest-first scatter
 	unsigned int *hist;              // 2 x 128: length-class histogram / bases, cursors
+	int2 *block_reads;               // per 1024-anchor block: reads of its first and last anchor (also used by the compaction)
 };
 size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *blocks_bytes);
 
@@ -56,6 +60,7 @@ struct CompactScratch {
 	unsigned long long *block_cnt;   // per 1024-anchor block record count; scanned in place
 	unsigned long long *tile_tmp;
 	unsigned long long *n_seeds;     // total records of the batch
+	const int2 *block_reads;         // PrepassScratch::block_reads of the same batch
 };
 size_t compact_scratch_bytes(int64_t max_anchors, size_t *flags_bytes, size_t *blocks_bytes);
 hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off,

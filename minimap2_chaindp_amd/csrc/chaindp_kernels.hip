@@ -128,7 +128,7 @@ __device__ __forceinline__ int seg_of_hi(uint32_t yhi) { return (int)((yhi >> 16
 // 76 M anchors), hence count -> scan -> emit.
 
 #define PRE_BLOCK 256
-#define PRE_PER_BLOCK 1024
+#define PRE_PER_BLOCK CHAINDP_BLOCK_ANCHORS
 #define PRE_WORDS (PRE_PER_BLOCK / 64)
 
 // largest r in [lo, hi] with off[r] <= g   (off is non-decreasing; empty reads are skipped over)
@@ -141,26 +141,36 @@ __device__ __forceinline__ int64_t read_of(const int64_t *__restrict__ off, int6
 	return lo;
 }
 
+// Reads that the first and the last anchor of every 1024-anchor block belong to.  The anchor-parallel kernels
+// of the prepass and of the compaction all cut the batch into the same blocks; a per-block binary search by one
+// thread (28 dependent loads before the block can start) was most of their run time.
+__global__ __launch_bounds__(256) void k_block_reads(int64_t n_reads, int64_t total, const int64_t *__restrict__ off, int2 *__restrict__ block_reads)
+{
+	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t g0 = b * PRE_PER_BLOCK;
+	if (g0 >= total) return;
+	const int64_t g1 = g0 + PRE_PER_BLOCK < total ? g0 + PRE_PER_BLOCK : total;
+	const int64_t rlo = read_of(off, 0, n_reads - 1, g0);
+	block_reads[b] = make_int2((int)rlo, (int)read_of(off, rlo, n_reads - 1, g1 - 1));
+}
+
 __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_reads, int64_t total,
                                                        const int64_t *__restrict__ off, const ulonglong2 *__restrict__ a,
                                                        unsigned long long *__restrict__ sumq, uint64_t *__restrict__ start_mask,
                                                        unsigned long long *__restrict__ block_cnt,
                                                        int32_t *__restrict__ f, int32_t *__restrict__ p, int32_t *__restrict__ v,
-                                                       int32_t *__restrict__ tg, uint8_t *__restrict__ flags)
+                                                       int32_t *__restrict__ tg, uint8_t *__restrict__ flags,
+                                                       const int2 *__restrict__ block_reads)
 {
-	__shared__ int64_t s_rlo, s_rhi;
 	__shared__ unsigned int s_sum, s_units, s_singles;
 	const int lane = threadIdx.x & 63;
 	const uint64_t maxx = (uint64_t)(int64_t)par.max_dist_x;
 	const int64_t g0 = (int64_t)blockIdx.x * PRE_PER_BLOCK;
 	const int64_t g1 = g0 + PRE_PER_BLOCK < total ? g0 + PRE_PER_BLOCK : total;
-	if (threadIdx.x == 0) {
-		s_rlo = read_of(off, 0, n_reads - 1, g0);
-		s_rhi = read_of(off, 0, n_reads - 1, g1 - 1);
-		s_sum = 0; s_units = 0; s_singles = 0;
-	}
+	if (threadIdx.x == 0) { s_sum = 0; s_units = 0; s_singles = 0; }
 	__syncthreads();
-	const int64_t rlo = s_rlo, rhi = s_rhi;
+	const int2 rr = block_reads[blockIdx.x];                       // reads of the block's first and last anchor (k_block_reads)
+	const int64_t rlo = rr.x, rhi = rr.y;
 	const bool one_read = rlo == rhi;
 	unsigned int w_sum = 0, w_units = 0, w_singles = 0;
 	for (int64_t gb = g0; gb < g1; gb += PRE_BLOCK) {
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(256) void k_build_lut(Params par, int64_t n_reads, 
 		for (int dd = threadIdx.x; dd <= par.bw; dd += blockDim.x) {
 			const int lg = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
 			const int lin = (int)((double)dd * .01 * avgd);
-			lut[r * lut_stride + dd] = (uint16_t)(int16_t)-(lin + (lg >> 1));      // stored negated: < 2^15 for bw <= 4095, q_span <= 255
+			lut[r * lut_stride + dd] = (uint16_t)(int16_t)(1 - (lin + (lg >> 1)));  // stored as 1 - cost (see fast_masks): |.| < 2^15 for bw <= 4095, q_span <= 255
 		}
 	}
 }
@@ -378,35 +388,6 @@ struct Pairs {
 	                 // (general/deep evaluation sets it; the fast evaluation leaves it to chunk_continues())
 	uint32_t dr;     // fast evaluation only: x_i - x_j per lane
 };
-
-// Fast variant (see k_chain_units): every difference is exact in 32 bits, same segment everywhere, cost from
-// the LDS table.  Slots that no anchor of this unit has been written to yet hold x = x_first - max_dist_x - 2
-// (set at unit start), so lanes with j < 0 fail the window test like any out-of-window lane.
-template <int RING>
-__device__ __forceinline__ Pairs eval_fast(const UnitCtx &c, uint32_t xi, int qi, int span, int i, int kb0)
-{
-	constexpr int MASK = RING - 1;
-	const int slot = (i - 1 - kb0 - c.lane) & MASK;
-	const uint4 e = *(const uint4*)(c.s_w + 4 * slot);
-	const uint32_t dr = xi - e.x;
-	const uint32_t dq = (uint32_t)qi - e.y;
-	const uint32_t maxx = (uint32_t)c.maxx;
-	const uint64_t m_win = __builtin_amdgcn_ballot_w64(dr - 1u < maxx);                  // chain.c:252 and dr != 0 (:257)
-	const uint64_t m_dq = __builtin_amdgcn_ballot_w64(dq - 1u < (uint32_t)c.mdq);        // dq > 0 (:257), dq <= both gaps (:258)
-	const uint32_t dd = absdiff_u32(dr, dq);
-	const uint64_t m_bw = __builtin_amdgcn_ballot_w64(dd <= (uint32_t)c.bw);             // chain.c:260
-	Pairs P;
-	P.ok = m_win & m_dq & m_bw;
-	int sc0 = (int)dq < (int)dr ? (int)dq : (int)dr;
-	sc0 = sc0 > span ? span : sc0;                                                       // chain.c:262-263
-	const uint32_t di = dd < (uint32_t)c.bw ? dd : (uint32_t)c.bw;
-	const int sc = sc0 + (int)e.z - (int)c.s_lut[di];                                    // chain.c:272-273 via the table
-	P.sc = __builtin_amdgcn_inverse_ballot_w64(P.ok) ? sc : INT_MIN;
-	P.pj = (int)e.w;
-	P.cont = false;
-	P.dr = dr;
-	return P;
-}
 
 // General variant: the reference's formulas in 64-bit arithmetic.  DEEP = the predecessors are older than the
 // ring and come from global memory.
@@ -471,14 +452,6 @@ __device__ __forceinline__ uint64_t low_mask64(int n)
 // ring go to LDS.  Marks on older targets matter only if the scan later reaches a deep chunk; ring chunks do
 // not write them (replay_far_marks does, on demand); deep chunks write all of theirs to the global array.
 // Returns true when the scan for anchor i is complete (break taken, or window / unit exhausted).
-// x sorted => dr grows with the lane: every lane is inside the window iff the last one is
-template <bool FASTEVAL>
-__device__ __forceinline__ bool chunk_continues(const UnitCtx &c, const Pairs &P)
-{
-	if constexpr (FASTEVAL) return (uint32_t)__builtin_amdgcn_readlane((int)P.dr, 63) <= (uint32_t)c.maxx;
-	else return P.cont;
-}
-
 // highest set bit of a 64-bit lane mask; -64 for an empty mask (s_flbit_i32_b64 returns -1), which still gives an
 // empty s_bfm_b64 mask because only the low 6 bits of the width are used
 __device__ __forceinline__ int highest_lane(uint64_t m)
@@ -488,7 +461,15 @@ __device__ __forceinline__ int highest_lane(uint64_t m)
 	return r ^ 63;
 }
 
-template <int RING, bool DEEP, bool FASTEVAL>
+// lowest set bit of a 64-bit lane mask; -1 for an empty mask
+__device__ __forceinline__ int lowest_lane(uint64_t m)
+{
+	int r;
+	asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(m));
+	return r;
+}
+
+template <int RING, bool DEEP>
 __device__ __forceinline__ bool apply_chunk(const UnitCtx &c, const Pairs &P, int i, int kb0, int &max_f, int &max_j, int &n_skip)
 {
 	constexpr int MASK = RING - 1;
@@ -529,7 +510,7 @@ __device__ __forceinline__ bool apply_chunk(const UnitCtx &c, const Pairs &P, in
 		need = need < 1 ? 1 : need;
 		if (cb >= need) return true;                               // break taken (chain.c:278-279)
 		n_skip = x + cb;
-		return !chunk_continues<FASTEVAL>(c, P);
+		return !P.cont;
 	}
 	// general: clamped walk via prefix min
 	const bool isA = __builtin_amdgcn_inverse_ballot_w64(A), isB = __builtin_amdgcn_inverse_ballot_w64(B);
@@ -545,23 +526,22 @@ __device__ __forceinline__ bool apply_chunk(const UnitCtx &c, const Pairs &P, in
 	}
 	if (m) return true;
 	n_skip = __builtin_amdgcn_readlane(x, 63);
-	return !chunk_continues<FASTEVAL>(c, P);
+	return !P.cont;
 }
 
 // Before the first deep chunk of anchor i: write the marks of the ring chunks whose targets are older than the
 // ring (skipped by apply_chunk<.., false>) into the global mark array.
-template <int RING, bool GEN>
-__device__ __forceinline__ void replay_far_marks(const UnitCtx &c, const ulonglong2 &an, int ii, uint32_t xi, int qi, int span, int i)
+template <int RING>
+__device__ __forceinline__ void replay_far_marks(const UnitCtx &c, const ulonglong2 &an, int ii, int qi, int span, int i)
 {
 	for (int kb0 = 0; kb0 + 64 <= RING && kb0 < i; kb0 += 64) {
-		Pairs P;
-		if constexpr (GEN) P = eval_general<RING, false>(c, an, ii, qi, span, i, kb0);
-		else P = eval_fast<RING>(c, xi, qi, span, i, kb0);
+		const Pairs P = eval_general<RING, false>(c, an, ii, qi, span, i, kb0);
 		if (__builtin_amdgcn_inverse_ballot_w64(P.ok) && P.pj >= 0 && P.pj < i - RING) c.tg[c.base + P.pj] = i;
 	}
 }
 
-template <int RING, bool GEN>
+// General variant of the unit loop: anything the fast variant (below) does not take.
+template <int RING>
 __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 {
 	constexpr int MASK = RING - 1;
@@ -590,7 +570,6 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 		int pend_slot = -1, pend_mf = 0, pend_vj = INT_MIN;
 		for (int ii = 0; ii < cnt; ++ii) {
 			const int i = tile0 + ii;                          // unit-relative index of the anchor being scored
-			const uint32_t xi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)an.x, ii);
 			const int qi = __builtin_amdgcn_readlane((int)(uint32_t)an.y, ii);
 			const int span = span_of_hi((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(an.y >> 32), ii));
 			int max_f = span, max_j = -1;
@@ -599,21 +578,19 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 				// runs for the unit's first anchor: every lane then fails the window / range test and nothing happens.
 				int n_skip = 0;
 				Pairs P0;
-				if constexpr (GEN) P0 = eval_general<RING, false>(c, an, ii, qi, span, i, 0);
-				else P0 = eval_fast<RING>(c, xi, qi, span, i, 0);
-				const bool done0 = apply_chunk<RING, false, !GEN>(c, P0, i, 0, max_f, max_j, n_skip);
+				P0 = eval_general<RING, false>(c, an, ii, qi, span, i, 0);
+				const bool done0 = apply_chunk<RING, false>(c, P0, i, 0, max_f, max_j, n_skip);
 				if (__builtin_expect(!done0 && i > 64, 0)) {
 					for (int kb0 = 64; kb0 < i; kb0 += 64) {
 						bool done;
 						if (kb0 + 64 <= RING) {
 							Pairs P;
-							if constexpr (GEN) P = eval_general<RING, false>(c, an, ii, qi, span, i, kb0);
-							else P = eval_fast<RING>(c, xi, qi, span, i, kb0);
-							done = apply_chunk<RING, false, !GEN>(c, P, i, kb0, max_f, max_j, n_skip);
+							P = eval_general<RING, false>(c, an, ii, qi, span, i, kb0);
+							done = apply_chunk<RING, false>(c, P, i, kb0, max_f, max_j, n_skip);
 						} else {
-							if (kb0 == RING) replay_far_marks<RING, GEN>(c, an, ii, xi, qi, span, i);
+							if (kb0 == RING) replay_far_marks<RING>(c, an, ii, qi, span, i);
 							const Pairs P = eval_general<RING, true>(c, an, ii, qi, span, i, kb0);
-							done = apply_chunk<RING, true, false>(c, P, i, kb0, max_f, max_j, n_skip);
+							done = apply_chunk<RING, true>(c, P, i, kb0, max_f, max_j, n_skip);
 						}
 						if (done) break;
 					}
@@ -624,7 +601,7 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 			wave_mem_fence();
 			if (lane == ii) {
 				*(uint4*)(c.s_w + 4 * (i & MASK)) = make_uint4((uint32_t)an.x, (uint32_t)an.y, (uint32_t)max_f, (uint32_t)max_j);
-				if constexpr (GEN) { c.s_xhi[i & MASK] = (uint32_t)(an.x >> 32); c.s_yhi[i & MASK] = (uint32_t)(an.y >> 32); }
+				c.s_xhi[i & MASK] = (uint32_t)(an.x >> 32); c.s_yhi[i & MASK] = (uint32_t)(an.y >> 32);
 				if (pend_slot >= 0) c.s_v[pend_slot] = vprev;
 			}
 			wave_mem_fence();
@@ -668,12 +645,14 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 // VALU and SALU issue, not by memory):
 //   * LDS is addressed with raw byte addresses (the kernel has no static LDS, so the dynamic segment starts at 0;
 //     launch_chain checks that), which lets constant offsets fold into the DS instructions;
-//   * the ring entry holds x.lo, qpos, f+1 and 4*p: with x_i-1, q_i-1 and span-1 as the per-anchor scalars, the
-//     range tests "1 <= d <= max" become single unsigned compares of d-1, |dr-dq| is unchanged, and
-//     min(dq,dr,span) + f = min3(dq-1,dr-1,span-1) + (f+1); 4*p is the byte offset of the mark to write;
+//   * the ring entry holds x.lo+1, qpos+1, f and 4*p: subtracting it from the raw x_i, q_i gives dr-1 and dq-1,
+//     so the range tests "1 <= d <= max" become single unsigned compares, |dr-dq| is unchanged, and
+//     min(dq,dr,span) + f - cost = min3(dq-1,dr-1,span-1) + f + (1-cost); 4*p is the byte offset of the mark to write;
+//   * the per-anchor scalars x_i, q_i, span come through the scalar cache (s_load, one anchor ahead) instead of
+//     v_readlane: the kernel is VALU-bound and the scalar side has room;
 //   * the three filters of chain.c:252-260 are one compare: max3(dr-1, sat(dq-1 + (max_x - max_q)),
 //     |dr-dq| + (max_x-1-bw)) < max_x (no wrap-around matters: when the first two are below max_x, so is |dr-dq|);
-//   * the cost table holds -cost as int16, so the score is one three-operand add;
+//   * the cost table holds 1-cost as int16, so the score is one three-operand add;
 //   * prefix-max lanes without a source read 0 instead of INT_MIN: the running max is >= q_span >= 0, so a
 //     floor of 0 changes nothing and saves the copy in front of the DPP chain;
 //   * v[] (chain.c:284) is not part of the recurrence at all: v[i] = max(f[i], v[p[i]]) is computed per 64-anchor
@@ -710,7 +689,7 @@ struct FastLds {
 	static constexpr uint32_t T_OFF = RB;                 // mark tags
 	static constexpr uint32_t V_OFF = RB + 4u * RING;     // v
 	static constexpr uint32_t DUMMY = 32u * RING;         // sink for lanes without a mark to write
-	static constexpr uint32_t LUT = 32u * RING + 16u;     // -cost table (int16)
+	static constexpr uint32_t LUT = 32u * RING + 16u;     // table of 1 - cost (int16)
 };
 
 struct FastK {
@@ -833,11 +812,67 @@ __device__ __forceinline__ void fast_more_chunks(const UnitCtx &c, const FastK &
 					if (P.ok && pj4 >= 0 && pj4 < lo4) c.tg[c.base + (pj4 >> 2)] = i;
 				}
 			}
-			const Pairs P = eval_general<RING, true>(c, an, ii, (int)(qm1 + 1u), spm1 + 1, i, kb0);
-			done = apply_chunk<RING, true, false>(c, P, i, kb0, max_f, max_j, n_skip);
+			const Pairs P = eval_general<RING, true>(c, an, ii, (int)qm1, spm1 + 1, i, kb0);
+			done = apply_chunk<RING, true>(c, P, i, kb0, max_f, max_j, n_skip);
 		}
 		if (done) break;
 	}
+}
+
+// One anchor of a tile: scan (chunk 0 inline, further chunks out of line), then the anchor enters the ring.
+// a_cur holds this anchor's mm128_t as four scalar dwords; a_next receives the next anchor's (scalar load issued here).
+template <int RING, bool SAMEGAP>
+__device__ __forceinline__ void fast_anchor_step(const UnitCtx &c, const FastK &k, const ulonglong2 &an, int tile0, int ii, const u32x4_t &a_cur,
+                                                 u32x4_t &a_next, const char *ap, uint32_t &off_next, uint32_t off_last, uint32_t waddr, uint4 W)
+{
+	const int i = tile0 + ii;                          // unit-relative index of the anchor being scored
+	const uint32_t xm1 = a_cur.x, qm1 = a_cur.z;       // ring entries hold x+1 and q+1
+	asm volatile("" :: "s"(a_cur.y));                  // x.hi is not needed, but its register must stay reserved until the load
+	                                                   // has landed (a reuse would force a wait right behind the s_load)
+	const int spm1 = span_of_hi(a_cur.w) - 1;
+	off_next = off_next + 16u < off_last ? off_next + 16u : off_last;
+	const int lo4 = max((i - RING) << 2, 0);           // byte offset of the oldest mark slot still in the ring
+	int max_f = spm1 + 1, max_j = -1, n_skip = 0;
+	// chunk 0 (the 64 nearest predecessors) settles most anchors.  It also runs for the unit's first anchors:
+	// slots not written yet fail the window test, so nothing happens on those lanes.  Written out with
+	// explicit exits so that the common path (break inside chunk 0) is straight-line scalar code.
+	{
+		const FastMasks m = fast_masks<RING, SAMEGAP>(k, (uint32_t)(i - 1) << 4, xm1, qm1, spm1, i, lo4, max_f);
+		// next anchor's scalars: issued only now (the address is made to depend on B), after this step's last LDS
+		// wait, so that no LDS wait of this step also waits for the scalar load
+		asm volatile("" : "+s"(off_next) : "s"(m.B));
+		a_next = *(const u32x4_t*)(ap + off_next);
+		const int hiA = highest_lane(m.A);
+		// every A lane precedes every B lane, or B is empty (s_ff1 gives -1, the largest unsigned).  With A empty and B
+		// not, hiA is -64 and the (equally correct) general walk runs.
+		if ((uint32_t)lowest_lane(m.B) > (uint32_t)hiA) {
+			if (hiA >= 0) {
+				max_f = __builtin_amdgcn_readlane(m.sc, hiA);
+				max_j = i - 1 - hiA;
+			}
+			n_skip = __builtin_popcountll(m.B);                // n_skip was 0: A lanes cannot lower it
+			if (n_skip > k.ms0) goto anchor_done;              // break taken at a B lane (chain.c:278-279)
+			if ((uint32_t)__builtin_amdgcn_readlane((int)m.drm1, 63) + 1u > k.M) goto anchor_done;   // window exhausted
+			fast_more_chunks<RING, SAMEGAP>(c, k, an, ii, i, xm1, qm1, spm1, lo4, max_f, max_j, n_skip);
+		} else {
+			// A and B lanes interleave (rare): own copy of the tail, so that the common path above shares no
+			// control flow (and no merged exit flags) with it
+			if (fast_walk_general(k, m, i - 1, max_f, max_j, n_skip)) goto anchor_done;
+			if ((uint32_t)__builtin_amdgcn_readlane((int)m.drm1, 63) + 1u > k.M) goto anchor_done;
+			fast_more_chunks<RING, SAMEGAP>(c, k, an, ii, i, xm1, qm1, spm1, lo4, max_f, max_j, n_skip);
+		}
+	}
+anchor_done:
+	// anchor i enters the ring (chain.c:283)
+	W.z = (uint32_t)max_f; W.w = (uint32_t)(max_j << 2);
+	wave_mem_fence();
+	{
+		// single-lane store with the exec mask set by hand: no branch in the IR, so the anchor loop has only
+		// wave-uniform control flow (exec is all ones here: 64-thread workgroups, uniform branches only)
+		u32x4_t w4; w4.x = W.x; w4.y = W.y; w4.z = W.z; w4.w = W.w;
+		asm volatile("s_bfm_b64 exec, 1, %0\n\tds_write_b128 %1, %2\n\ts_mov_b64 exec, -1" :: "s"(ii), "v"(waddr), "v"(w4) : "memory");
+	}
+	wave_mem_fence();
 }
 
 template <int RING, bool SAMEGAP>
@@ -874,59 +909,32 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 		if (cnt == 0) break;
 		x_carry = readlane_u64(an.x, 63);
 
-		const uint32_t xm1v = (uint32_t)an.x - 1u, qm1v = (uint32_t)an.y - 1u;
-		const int spm1v = span_of_hi((uint32_t)(an.y >> 32)) - 1;
+		// the per-anchor scalars (x_i-1, q_i-1, span-1) come through the scalar cache, one anchor ahead of their use:
+		// SMEM + SALU work instead of three v_readlane (the kernel is VALU-bound)
+		const char *ap = (const char*)(c.a + (c.base + tile0));
+		const uint32_t off_last = (uint32_t)(cnt - 1) << 4;
+		uint32_t off_next = 0;
+		u32x4_t a_cur = *(const u32x4_t*)ap;
 		const uint32_t waddr = (uint32_t)((tile0 + lane) & MASK) << 4;
 		uint4 W;
-		W.x = (uint32_t)an.x; W.y = (uint32_t)an.y;
-		for (int ii = 0; ii < cnt; ++ii) {
-			const int i = tile0 + ii;                          // unit-relative index of the anchor being scored
-			const uint32_t xm1 = (uint32_t)__builtin_amdgcn_readlane((int)xm1v, ii);
-			const uint32_t qm1 = (uint32_t)__builtin_amdgcn_readlane((int)qm1v, ii);
-			const int spm1 = __builtin_amdgcn_readlane(spm1v, ii);
-			const int lo4 = max((i - RING) << 2, 0);           // byte offset of the oldest mark slot still in the ring
-			int max_f = spm1 + 1, max_j = -1, n_skip = 0;
-			// chunk 0 (the 64 nearest predecessors) settles most anchors.  It also runs for the unit's first anchors:
-			// slots not written yet fail the window test, so nothing happens on those lanes.  Written out with
-			// explicit exits so that the common path (break inside chunk 0) is straight-line scalar code.
-			{
-				const FastMasks m = fast_masks<RING, SAMEGAP>(k, (uint32_t)(i - 1) << 4, xm1, qm1, spm1, i, lo4, max_f);
-				const int hiA = highest_lane(m.A);
-				if ((m.B & low_mask64(hiA)) == 0) {                    // every A lane precedes every B lane (or one set is empty)
-					if (hiA >= 0) {
-						max_f = __builtin_amdgcn_readlane(m.sc, hiA);
-						max_j = i - 1 - hiA;
-					}
-					n_skip = __builtin_popcountll(m.B);                // n_skip was 0: A lanes cannot lower it
-					if (n_skip > k.ms0) goto anchor_done;              // break taken at a B lane (chain.c:278-279)
-					if ((uint32_t)__builtin_amdgcn_readlane((int)m.drm1, 63) + 1u > k.M) goto anchor_done;   // window exhausted
-					fast_more_chunks<RING, SAMEGAP>(c, k, an, ii, i, xm1, qm1, spm1, lo4, max_f, max_j, n_skip);
-				} else {
-					// A and B lanes interleave (rare): own copy of the tail, so that the common path above shares no
-					// control flow (and no merged exit flags) with it
-					if (fast_walk_general(k, m, i - 1, max_f, max_j, n_skip)) goto anchor_done;
-					if ((uint32_t)__builtin_amdgcn_readlane((int)m.drm1, 63) + 1u > k.M) goto anchor_done;
-					fast_more_chunks<RING, SAMEGAP>(c, k, an, ii, i, xm1, qm1, spm1, lo4, max_f, max_j, n_skip);
-				}
+		W.x = (uint32_t)an.x + 1u; W.y = (uint32_t)an.y + 1u;
+		// two steps per trip with the scalar registers swapped, so that the prefetched anchor is used in place (a copy at
+		// the end of the step would need the load to have landed by then)
+		{
+			u32x4_t a_alt;
+			int ii = 0;
+			for (; ii + 2 <= cnt; ii += 2) {
+				fast_anchor_step<RING, SAMEGAP>(c, k, an, tile0, ii, a_cur, a_alt, ap, off_next, off_last, waddr, W);
+				fast_anchor_step<RING, SAMEGAP>(c, k, an, tile0, ii + 1, a_alt, a_cur, ap, off_next, off_last, waddr, W);
 			}
-		anchor_done:
-			// anchor i enters the ring (chain.c:283)
-			W.z = (uint32_t)(max_f + 1); W.w = (uint32_t)(max_j << 2);
-			wave_mem_fence();
-			{
-				// single-lane store with the exec mask set by hand: no branch in the IR, so the anchor loop has only
-				// wave-uniform control flow (exec is all ones here: 64-thread workgroups, uniform branches only)
-				u32x4_t w4; w4.x = W.x; w4.y = W.y; w4.z = W.z; w4.w = W.w;
-				asm volatile("s_bfm_b64 exec, 1, %0\n\tds_write_b128 %1, %2\n\ts_mov_b64 exec, -1" :: "s"(ii), "v"(waddr), "v"(w4) : "memory");
-			}
-			wave_mem_fence();
+			if (ii < cnt) fast_anchor_step<RING, SAMEGAP>(c, k, an, tile0, ii, a_cur, a_alt, ap, off_next, off_last, waddr, W);
 		}
 		// tile flush: v (chain.c:284) by pointer doubling, then f/p/v and the compaction helpers
 		{
 			int fi = 0, pi = -1, val = 0, ptr = -1;
 			if (lane < cnt) {
 				const int2 zw = lds_load_b64(waddr + 8u);
-				fi = zw.x - 1; pi = zw.y >> 2;
+				fi = zw.x; pi = zw.y >> 2;
 				val = fi; ptr = pi;
 			}
 			const bool ext = ptr >= 0 && ptr < tile0;               // predecessor in an earlier tile: its v is final
@@ -1016,12 +1024,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 		if (!general) {
 			const uint4 *src = (const uint4*)(lut + (int64_t)u.read * lut_stride);   // lut_stride is a multiple of 8 entries (16 B)
 			for (int k = lane; k * 8 < lut_stride; k += 64) ((uint4*)s_lut)[k] = src[k];
-			const uint32_t x_none = (uint32_t)a[u.start].x - (uint32_t)c.maxx - 2u;  // "no anchor here yet": fails the window test
+			const uint32_t x_none = (uint32_t)a[u.start].x - (uint32_t)c.maxx - 1u;  // "no anchor here yet" (x+1 encoding): fails the window test
 			for (int k = lane; k < RING; k += 64) *(uint4*)(c.s_w + 4 * k) = make_uint4(x_none, 0u, 0u, 0xfffffffcu);
 		}
 		wave_mem_fence();
 		// u.len bounds the unit (next unit's start or the read's end); run_unit finds the true end at the first gap
-		if (general) run_unit<RING, true>(c, (int64_t)u.len);
+		if (general) run_unit<RING>(c, (int64_t)u.len);
 		else if (par.max_dist_y >= par.max_dist_x) run_unit_fast<RING, true>(c, (int64_t)u.len);
 		else run_unit_fast<RING, false>(c, (int64_t)u.len);
 	}
@@ -1039,8 +1047,9 @@ hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, in
 	if ((e = hipMemsetAsync(d_first_child, 0x7f, (size_t)total * 4, st)) != hipSuccess) return e;   // "no child" (chaindp_compact.hip)
 	const int64_t blocks = (total + PRE_PER_BLOCK - 1) / PRE_PER_BLOCK;
 	const int64_t words = (total + 63) / 64;
+	hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, st, n_reads, total, d_off, sc.block_reads);
 	hipLaunchKernelGGL(k_prepass, dim3((unsigned)blocks), dim3(PRE_BLOCK), 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a,
-	                   d_sumq, sc.start_mask, sc.block_cnt, d_f, d_p, d_v, d_tg, d_flags);
+	                   d_sumq, sc.start_mask, sc.block_cnt, d_f, d_p, d_v, d_tg, d_flags, sc.block_reads);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, d_counters)) != hipSuccess) return e;
 	if ((e = hipMemsetAsync(sc.hist, 0, 2 * UNIT_CLASSES * sizeof(unsigned int), st)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_emit_units, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, n_reads, words, d_off,
