@@ -110,9 +110,10 @@ hipError_t launch_scan_u64(hipStream_t st, int64_t n, unsigned long long *d_data
 #define NO_CHILD 0x7f7f7f7f   // hipMemsetAsync(0x7f) pattern; larger than any read-relative index in use
 
 // C1 happens inside the DP kernel's tile flush (k_chain_units) and the prepass (singletons): they set bit1 of
-// flags[] ("emitted at its own step") and feed first_child[] with atomicMin for predecessors that are not.
-// C2: late bit and per-block record counts.  first_child[q] == k can only hold for a q that is not emitted at
-// its own step, so no further look at v[q]/p[q] is needed.
+// flags[] ("emitted at its own step"), bit2 ("my predecessor is not emitted at its own step, so I may be its first
+// child") and feed first_child[] with atomicMin for exactly those predecessors.
+// C2: late bit and per-block record counts.  Only anchors with bit2 look at p[] and first_child[]; for everything
+// else this pass reads one byte per anchor.  Each thread owns 4 consecutive anchors.
 __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t total,
                                                      const int64_t *__restrict__ off, const int32_t *__restrict__ p,
                                                      const int32_t *__restrict__ first_child,
@@ -126,17 +127,24 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t to
 	if (threadIdx.x == 0) s_cnt = 0;
 	__syncthreads();
 	block_read_range(block_reads, rlo, rhi);
+	const int64_t g = g0 + 4 * (int64_t)threadIdx.x;
 	unsigned int mine = 0;
-	for (int64_t g = g0 + threadIdx.x; g < g1; g += CMP_BLOCK) {
-		const int32_t q = p[g];
-		const int self = (flags[g] >> 1) & 1;
-		int late = 0;
-		if (q >= 0) {
-			const int64_t rs = off[rlo == rhi ? rlo : read_of_c(off, rlo, rhi, g)];
-			late = first_child[rs + q] == (int32_t)(g - rs);
-			if (late) flags[g] = (uint8_t)3;                    // q >= 0 implies self
+	if (g < g1) {
+		uint32_t w = *(const uint32_t*)(flags + g);               // 4 flag bytes (the array is padded to 16 B)
+		const int n = g1 - g < 4 ? (int)(g1 - g) : 4;
+		if (n < 4) w &= (1u << (8 * n)) - 1u;
+		if (w & 0x04040404u) {                                     // rare: someone here may be a first child
+			for (int e = 0; e < n; ++e) {
+				if (!((w >> (8 * e)) & 4u)) continue;
+				const int64_t ge = g + e;
+				const int64_t rs = off[rlo == rhi ? rlo : read_of_c(off, rlo, rhi, ge)];
+				if (first_child[rs + p[ge]] == (int32_t)(ge - rs)) {
+					w |= 1u << (8 * e);
+					flags[ge] = (uint8_t)((w >> (8 * e)) & 0xffu);
+				}
+			}
 		}
-		mine += (unsigned int)(late + self);
+		mine = (unsigned int)__builtin_popcount(w & 0x03030303u);  // late + self per anchor
 	}
 	for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d, 64);
 	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t to
 }
 
 // C3: positions.  block_base = exclusive scan of block_cnt.  Writes batch-global ids and seeds_off[r] at every
-// read's first anchor (empty reads in front of it share the value).
+// read's first anchor (empty reads in front of it share the value).  4 consecutive anchors per thread.
 __global__ __launch_bounds__(CMP_BLOCK) void k_positions(int64_t n_reads, int64_t total, const int64_t *__restrict__ off,
                                                          const int32_t *__restrict__ p, const uint8_t *__restrict__ flags,
                                                          const unsigned long long *__restrict__ block_base,
@@ -158,28 +166,36 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_positions(int64_t n_reads, int64_
 	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
 	int64_t rlo, rhi;
 	block_read_range(block_reads, rlo, rhi);
-	unsigned int carry = (unsigned int)block_base[blockIdx.x];
-	for (int64_t gb = g0; gb < g1; gb += CMP_BLOCK) {
-		const int64_t g = gb + threadIdx.x;
-		const int fl = g < g1 ? flags[g] : 0;
-		const int c = (fl & 1) + (fl >> 1);
-		const uint64_t b0 = __builtin_amdgcn_ballot_w64(c & 1), b1 = __builtin_amdgcn_ballot_w64(c & 2);
-		const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
-		const unsigned int in_wave = __builtin_popcountll(b0 & below) + 2 * __builtin_popcountll(b1 & below);
-		if (lane == 0) s_w[wave] = __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1);
-		__syncthreads();
-		unsigned int woff = 0, tot = 0;
-		for (int w = 0; w < 4; ++w) { const unsigned int t = s_w[w]; if (w < wave) woff += t; tot += t; }
-		const unsigned int pos = carry + woff + in_wave;
-		if (g < g1) {
-			const int64_t r = rlo == rhi ? rlo : read_of_c(off, rlo, rhi, g);
-			const int64_t rs = off[r];
-			if (fl & 1) id[rs + p[g]] = (int32_t)pos;
-			if (fl & 2) id[g] = (int32_t)(pos + (fl & 1));
-			if (g == rs) for (int64_t rr = r; rr >= 0 && off[rr] == rs; --rr) seeds_off[rr] = (int64_t)pos;
-		}
-		carry += tot;
-		__syncthreads();
+	const int64_t g = g0 + 4 * (int64_t)threadIdx.x;
+	uint32_t w = 0;
+	int n = 0;
+	if (g < g1) {
+		w = *(const uint32_t*)(flags + g);
+		n = g1 - g < 4 ? (int)(g1 - g) : 4;
+		if (n < 4) w &= (1u << (8 * n)) - 1u;
+	}
+	const unsigned int mine = (unsigned int)__builtin_popcount(w & 0x03030303u);
+	unsigned int incl = mine;
+	for (int d = 1; d < 64; d <<= 1) { const unsigned int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+	if (lane == 63) s_w[wave] = incl;
+	__syncthreads();
+	unsigned int pos = (unsigned int)block_base[blockIdx.x] + incl - mine;
+	for (int k = 0; k < wave; ++k) pos += s_w[k];
+	if (n == 0) return;
+	if ((w & 0x03030303u) == 0x02020202u && n == 4 && rlo == rhi && g != off[rlo]) {
+		*(int4*)(id + g) = make_int4((int)pos, (int)pos + 1, (int)pos + 2, (int)pos + 3);   // the common case: four own-step records
+		return;
+	}
+	int64_t r = rlo == rhi ? rlo : read_of_c(off, rlo, rhi, g);
+	for (int e = 0; e < n; ++e) {
+		const int64_t ge = g + e;
+		const unsigned int fl = (w >> (8 * e)) & 0xffu;
+		while (ge >= off[r + 1]) ++r;                              // reads only move forward inside the thread's 4 anchors
+		const int64_t rs = off[r];
+		if (fl & 1) id[rs + p[ge]] = (int32_t)pos;
+		if (fl & 2) id[ge] = (int32_t)(pos + (fl & 1));
+		if (ge == rs) for (int64_t rr = r; rr >= 0 && off[rr] == rs; --rr) seeds_off[rr] = (int64_t)pos;
+		pos += (fl & 1) + ((fl >> 1) & 1);
 	}
 }
 

@@ -627,13 +627,14 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 			// Compaction (chain.c:286-317) needs, for every anchor that is not emitted at its own step, its
 			// first child; while f/p/v of the tile are at hand, record "emitted at own step" and feed that min.
 			const int q = fp.y;
+			int maybe_first = 0;
 			if (q >= 0) {
 				int vq, pq;
 				if (tile0 + cnt - 1 - q < RING) { vq = c.s_v[q & MASK]; pq = (int)c.s_w[4 * (q & MASK) + 3]; }
 				else { vq = c.v[c.base + q]; pq = c.p[c.base + q]; }
-				if (!(vq >= c.min_sc || pq >= 0)) atomicMin(&c.first_child[c.base + q], c.rel0 + tile0 + lane);
+				if (!(vq >= c.min_sc || pq >= 0)) { atomicMin(&c.first_child[c.base + q], c.rel0 + tile0 + lane); maybe_first = 4; }
 			}
-			c.flags[gi] = (uint8_t)((vi >= c.min_sc || q >= 0) ? 2 : 0);
+			c.flags[gi] = (uint8_t)(((vi >= c.min_sc || q >= 0) ? 2 : 0) | maybe_first);
 		}
 		if (cnt < 64) break;
 	}
@@ -960,15 +961,16 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 				c.v[gi] = val;
 				// Compaction (chain.c:286-317) needs, for every anchor that is not emitted at its own step, its
 				// first child; while f/p/v of the tile are at hand, record "emitted at own step" and feed that min.
+				int maybe_first = 0;
 				if (pi >= 0) {
 					int vq, pq;
 					if (tile0 + cnt - 1 - pi < RING) {
 						vq = lds_load_b32(L::V_OFF + ((uint32_t)(pi & MASK) << 2));
 						pq = lds_load_b32(((uint32_t)(pi & MASK) << 4) + 12u);
 					} else { vq = c.v[c.base + pi]; pq = c.p[c.base + pi]; }
-					if (!(vq >= c.min_sc || pq >= 0)) atomicMin(&c.first_child[c.base + pi], c.rel0 + tile0 + lane);
+					if (!(vq >= c.min_sc || pq >= 0)) { atomicMin(&c.first_child[c.base + pi], c.rel0 + tile0 + lane); maybe_first = 4; }
 				}
-				c.flags[gi] = (uint8_t)((val >= c.min_sc || pi >= 0) ? 2 : 0);
+				c.flags[gi] = (uint8_t)(((val >= c.min_sc || pi >= 0) ? 2 : 0) | maybe_first);
 			}
 		}
 		if (cnt < 64) break;
