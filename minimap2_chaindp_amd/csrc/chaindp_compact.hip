@@ -113,89 +113,103 @@ hipError_t launch_scan_u64(hipStream_t st, int64_t n, unsigned long long *d_data
 // flags[] ("emitted at its own step"), bit2 ("my predecessor is not emitted at its own step, so I may be its first
 // child") and feed first_child[] with atomicMin for exactly those predecessors.
 // C2: late bit and per-block record counts.  Only anchors with bit2 look at p[] and first_child[]; for everything
-// else this pass reads one byte per anchor.  Each thread owns 4 consecutive anchors.
+// else this pass reads one byte per anchor.  One wave per 1024-anchor block, 16 consecutive anchors per lane (one
+// 16-byte load in flight per lane; a 256-thread block per 1024 anchors was bound by its own start-up latency).
+__device__ __forceinline__ unsigned int flag_word(const uint4 &v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
+
 __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t total,
                                                      const int64_t *__restrict__ off, const int32_t *__restrict__ p,
                                                      const int32_t *__restrict__ first_child,
                                                      uint8_t *__restrict__ flags, unsigned long long *__restrict__ block_cnt,
                                                      const int2 *__restrict__ block_reads)
 {
-	__shared__ unsigned int s_cnt;
-	const int64_t g0 = (int64_t)blockIdx.x * CMP_PER_BLOCK;
+	const int lane = threadIdx.x & 63;
+	const int64_t blk = (int64_t)blockIdx.x * (CMP_BLOCK / 64) + (threadIdx.x >> 6);
+	const int64_t g0 = blk * CMP_PER_BLOCK;
+	if (g0 >= total) return;
 	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
-	int64_t rlo, rhi;
-	if (threadIdx.x == 0) s_cnt = 0;
-	__syncthreads();
-	block_read_range(block_reads, rlo, rhi);
-	const int64_t g = g0 + 4 * (int64_t)threadIdx.x;
+	const int64_t g = g0 + 16 * lane;
 	unsigned int mine = 0;
 	if (g < g1) {
-		uint32_t w = *(const uint32_t*)(flags + g);               // 4 flag bytes (the array is padded to 16 B)
-		const int n = g1 - g < 4 ? (int)(g1 - g) : 4;
-		if (n < 4) w &= (1u << (8 * n)) - 1u;
-		if (w & 0x04040404u) {                                     // rare: someone here may be a first child
+		uint4 v = *(const uint4*)(flags + g);                      // 16 flag bytes (the array is padded to 16 B)
+		const int n = g1 - g < 16 ? (int)(g1 - g) : 16;
+		if ((v.x | v.y | v.z | v.w) & 0x04040404u) {               // rare: someone here may be a first child
+			const int2 rr = block_reads[blk];
 			for (int e = 0; e < n; ++e) {
-				if (!((w >> (8 * e)) & 4u)) continue;
+				const unsigned int fl = (flag_word(v, e >> 2) >> (8 * (e & 3))) & 0xffu;
+				if (!(fl & 4u)) continue;
 				const int64_t ge = g + e;
-				const int64_t rs = off[rlo == rhi ? rlo : read_of_c(off, rlo, rhi, ge)];
+				const int64_t rs = off[rr.x == rr.y ? rr.x : read_of_c(off, rr.x, rr.y, ge)];
 				if (first_child[rs + p[ge]] == (int32_t)(ge - rs)) {
-					w |= 1u << (8 * e);
-					flags[ge] = (uint8_t)((w >> (8 * e)) & 0xffu);
+					flags[ge] = (uint8_t)(fl | 1u);
+					const unsigned int bit = 1u << (8 * (e & 3));
+					if ((e >> 2) == 0) v.x |= bit; else if ((e >> 2) == 1) v.y |= bit; else if ((e >> 2) == 2) v.z |= bit; else v.w |= bit;
 				}
 			}
 		}
-		mine = (unsigned int)__builtin_popcount(w & 0x03030303u);  // late + self per anchor
+		for (int k = 0; k < 4; ++k) {
+			unsigned int w = flag_word(v, k);
+			const int left = n - 4 * k;
+			if (left <= 0) w = 0; else if (left < 4) w &= (1u << (8 * left)) - 1u;
+			mine += (unsigned int)__builtin_popcount(w & 0x03030303u);    // late + self per anchor
+		}
 	}
 	for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d, 64);
-	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
-	__syncthreads();
-	if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_cnt;
+	if (lane == 0) block_cnt[blk] = mine;
 }
 
 // C3: positions.  block_base = exclusive scan of block_cnt.  Writes batch-global ids and seeds_off[r] at every
-// read's first anchor (empty reads in front of it share the value).  4 consecutive anchors per thread.
+// read's first anchor (empty reads in front of it share the value).  One wave per 1024-anchor block in four
+// passes of 256 anchors, 4 consecutive anchors per lane: the four flag loads are issued together, the id stores of
+// a pass are 1 KB contiguous per wave (16 anchors per lane would scatter 16-byte stores at a 64-byte stride).
 __global__ __launch_bounds__(CMP_BLOCK) void k_positions(int64_t n_reads, int64_t total, const int64_t *__restrict__ off,
                                                          const int32_t *__restrict__ p, const uint8_t *__restrict__ flags,
                                                          const unsigned long long *__restrict__ block_base,
                                                          int32_t *__restrict__ id, int64_t *__restrict__ seeds_off,
                                                          const int2 *__restrict__ block_reads)
 {
-	__shared__ unsigned int s_w[4];
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int64_t g0 = (int64_t)blockIdx.x * CMP_PER_BLOCK;
+	const int lane = threadIdx.x & 63;
+	const int64_t blk = (int64_t)blockIdx.x * (CMP_BLOCK / 64) + (threadIdx.x >> 6);
+	const int64_t g0 = blk * CMP_PER_BLOCK;
+	if (g0 >= total) return;
 	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
-	int64_t rlo, rhi;
-	block_read_range(block_reads, rlo, rhi);
-	const int64_t g = g0 + 4 * (int64_t)threadIdx.x;
-	uint32_t w = 0;
-	int n = 0;
-	if (g < g1) {
-		w = *(const uint32_t*)(flags + g);
-		n = g1 - g < 4 ? (int)(g1 - g) : 4;
-		if (n < 4) w &= (1u << (8 * n)) - 1u;
+	const int2 rr = block_reads[blk];
+	const int64_t rlo = rr.x, rhi = rr.y;
+	uint32_t w[4];
+	int n[4];
+	for (int it = 0; it < 4; ++it) {
+		const int64_t g = g0 + 256 * it + 4 * lane;
+		w[it] = 0; n[it] = 0;
+		if (g < g1) {
+			w[it] = *(const uint32_t*)(flags + g);                 // the array is padded to 16 B
+			n[it] = g1 - g < 4 ? (int)(g1 - g) : 4;
+			if (n[it] < 4) w[it] &= (1u << (8 * n[it])) - 1u;
+		}
 	}
-	const unsigned int mine = (unsigned int)__builtin_popcount(w & 0x03030303u);
-	unsigned int incl = mine;
-	for (int d = 1; d < 64; d <<= 1) { const unsigned int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-	if (lane == 63) s_w[wave] = incl;
-	__syncthreads();
-	unsigned int pos = (unsigned int)block_base[blockIdx.x] + incl - mine;
-	for (int k = 0; k < wave; ++k) pos += s_w[k];
-	if (n == 0) return;
-	if ((w & 0x03030303u) == 0x02020202u && n == 4 && rlo == rhi && g != off[rlo]) {
-		*(int4*)(id + g) = make_int4((int)pos, (int)pos + 1, (int)pos + 2, (int)pos + 3);   // the common case: four own-step records
-		return;
-	}
-	int64_t r = rlo == rhi ? rlo : read_of_c(off, rlo, rhi, g);
-	for (int e = 0; e < n; ++e) {
-		const int64_t ge = g + e;
-		const unsigned int fl = (w >> (8 * e)) & 0xffu;
-		while (ge >= off[r + 1]) ++r;                              // reads only move forward inside the thread's 4 anchors
-		const int64_t rs = off[r];
-		if (fl & 1) id[rs + p[ge]] = (int32_t)pos;
-		if (fl & 2) id[ge] = (int32_t)(pos + (fl & 1));
-		if (ge == rs) for (int64_t rr = r; rr >= 0 && off[rr] == rs; --rr) seeds_off[rr] = (int64_t)pos;
-		pos += (fl & 1) + ((fl >> 1) & 1);
+	unsigned int carry = (unsigned int)block_base[blk];
+	for (int it = 0; it < 4; ++it) {
+		const int64_t g = g0 + 256 * it + 4 * lane;
+		const unsigned int mine = (unsigned int)__builtin_popcount(w[it] & 0x03030303u);
+		unsigned int incl = mine;
+		for (int d = 1; d < 64; d <<= 1) { const unsigned int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+		unsigned int pos = carry + incl - mine;
+		carry += __shfl(incl, 63, 64);
+		if (n[it] == 0) continue;
+		if ((w[it] & 0x03030303u) == 0x02020202u && rlo == rhi && g != off[rlo]) {
+			*(int4*)(id + g) = make_int4((int)pos, (int)pos + 1, (int)pos + 2, (int)pos + 3);   // the common case: four own-step records
+			continue;
+		}
+		int64_t r = rlo == rhi ? rlo : read_of_c(off, rlo, rhi, g);
+		for (int e = 0; e < n[it]; ++e) {
+			const int64_t ge = g + e;
+			const unsigned int fl = (w[it] >> (8 * e)) & 0xffu;
+			while (ge >= off[r + 1]) ++r;                          // reads only move forward inside the lane's 4 anchors
+			const int64_t rs = off[r];
+			if (fl & 1) id[rs + p[ge]] = (int32_t)pos;
+			if (fl & 2) id[ge] = (int32_t)(pos + (fl & 1));
+			if (ge == rs) for (int64_t q = r; q >= 0 && off[q] == rs; --q) seeds_off[q] = (int64_t)pos;
+			pos += (fl & 1) + ((fl >> 1) & 1);
+		}
 	}
 }
 
@@ -265,9 +279,10 @@ hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, in
 	if (total <= 0) return hipMemsetAsync(d_seeds_off, 0, (size_t)(n_reads + 1) * sizeof(int64_t), st);
 	const int64_t blocks = (total + CMP_PER_BLOCK - 1) / CMP_PER_BLOCK;
 	const dim3 g((unsigned)blocks), b(CMP_BLOCK);
-	hipLaunchKernelGGL(k_count, g, b, 0, st, n_reads, total, d_off, d_p, d_first_child, sc.flags, sc.block_cnt, sc.block_reads);
+	const dim3 gw((unsigned)((blocks + CMP_BLOCK / 64 - 1) / (CMP_BLOCK / 64)));    // one wave per 1024-anchor block
+	hipLaunchKernelGGL(k_count, gw, b, 0, st, n_reads, total, d_off, d_p, d_first_child, sc.flags, sc.block_cnt, sc.block_reads);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, sc.n_seeds)) != hipSuccess) return e;
-	hipLaunchKernelGGL(k_positions, g, b, 0, st, n_reads, total, d_off, d_p, sc.flags, sc.block_cnt, d_id, d_seeds_off, sc.block_reads);
+	hipLaunchKernelGGL(k_positions, gw, b, 0, st, n_reads, total, d_off, d_p, sc.flags, sc.block_cnt, d_id, d_seeds_off, sc.block_reads);
 	hipLaunchKernelGGL(k_finish_offsets, dim3(1), dim3(1), 0, st, n_reads, total, d_off, sc.n_seeds, d_seeds_off);
 	hipLaunchKernelGGL(k_write_seeds, g, b, 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a, d_f, d_p, d_v, sc.flags, d_id,
 	                   d_seeds_off, (SeedRec*)d_seeds, sc.block_reads);
