@@ -31,7 +31,8 @@ struct chaindp_ctx {
 	int32_t *d_n_segs = nullptr;
 	int32_t *d_f = nullptr, *d_p = nullptr, *d_v = nullptr;
 	// scratch
-	int32_t *d_tg = nullptr;
+	unsigned long long *d_tg = nullptr;   // deep-path marks, tagged with the run epoch (never re-initialised)
+	uint32_t epoch = 0;
 	unsigned long long *d_sumq = nullptr;
 	Unit *d_units = nullptr;
 	unsigned long long *d_counters = nullptr;
@@ -133,7 +134,8 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_f, na * 4);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_p, na * 4);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_v, na * 4);
-	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_tg, na * 4);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_tg, na * 8);
+	if (e == hipSuccess) e = hipMemset(ctx->d_tg, 0, na * 8);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_sumq, nr * 8);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_units, (na / 2 + 1) * sizeof(Unit));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 2 * sizeof(unsigned long long));
@@ -200,8 +202,7 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		es.n = 3;
 	}
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[0], st));
-	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, d_f, d_p, d_v, ctx->d_tg,
-	                                     ctx->d_first_child, ctx->cmp.flags));
+	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, d_f, d_p, d_v, ctx->cmp.flags));
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[1], st));
 	// per-read gap-cost table for the fast variant (skipped when the table would not apply)
 	uint16_t *lut = nullptr;
@@ -219,8 +220,12 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		lut = ctx->d_lut;
 		HIP_TRY(ctx, chaindp::launch_lut(st, q, n_reads, d_off, ctx->d_sumq, lut_stride, lut));
 	}
+	if (++ctx->epoch == 0) {                                       // 2^32 runs: start the mark epochs over
+		HIP_TRY(ctx, hipMemsetAsync(ctx->d_tg, 0, (size_t)ctx->cap_anchors * 8, st));
+		ctx->epoch = 1;
+	}
 	HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, total / 2, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_units,
-	                                   ctx->d_counters, d_f, d_p, d_v, ctx->d_tg, ctx->d_first_child, ctx->cmp.flags));
+	                                   ctx->d_counters, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags));
 	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[2], st)); ctx->pending.push_back(es); }
 	ctx->stats[2] = total; ctx->stats[3] = n_reads;
 	return CHAINDP_OK;

@@ -107,7 +107,6 @@ hipError_t launch_scan_u64(hipStream_t st, int64_t n, unsigned long long *d_data
 
 // ---------------------------------------------------------------- compaction
 
-#define NO_CHILD 0x7f7f7f7f   // hipMemsetAsync(0x7f) pattern; larger than any read-relative index in use
 
 // C1 happens inside the DP kernel's tile flush (k_chain_units) and the prepass (singletons): they set bit1 of
 // flags[] ("emitted at its own step"), bit2 ("my predecessor is not emitted at its own step, so I may be its first

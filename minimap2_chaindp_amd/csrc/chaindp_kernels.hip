@@ -27,6 +27,8 @@
 
 namespace chaindp {
 
+#define NO_CHILD 0x7f7f7f7f   // first_child[]: larger than any read-relative index in use
+
 // ---------------------------------------------------------------- wave primitives (wave64, DPP)
 
 // dpp_ctrl encodings (gfx9 family): row_shr:n = 0x110+n, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_rea
                                                        unsigned long long *__restrict__ sumq, uint64_t *__restrict__ start_mask,
                                                        unsigned long long *__restrict__ block_cnt,
                                                        int32_t *__restrict__ f, int32_t *__restrict__ p, int32_t *__restrict__ v,
-                                                       int32_t *__restrict__ tg, uint8_t *__restrict__ flags,
+                                                       uint8_t *__restrict__ flags,
                                                        const int2 *__restrict__ block_reads)
 {
 	__shared__ unsigned int s_sum, s_units, s_singles;
@@ -188,7 +190,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_rea
 			start = g == rs || an.x - a[g - 1].x > maxx;
 			const bool next_starts = g + 1 >= re || a[g + 1].x - an.x > maxx;
 			single = start && next_starts;
-			tg[g] = -1;
 			if (single) {                                          // chain.c:251,283-284 with an empty window
 				f[g] = span; p[g] = -1; v[g] = span;
 				flags[g] = (uint8_t)(span >= par.min_sc ? 2 : 0);  // emitted at its own step iff v >= min_sc (chain.c:304)
@@ -362,7 +363,9 @@ __device__ __forceinline__ uint32_t absdiff_u32(uint32_t x, uint32_t y)
 // During step i the ring holds anchors i-RING .. i-1 (entry i is written at the end of step i).
 struct UnitCtx {
 	const ulonglong2 *a;
-	int32_t *f, *p, *v, *tg;
+	int32_t *f, *p, *v;
+	unsigned long long *tg;   // global mark array (deep path): (run epoch << 32 | tag), so it is never re-initialised
+	unsigned long long tg_hi; // run epoch << 32
 	int32_t *first_child;   // compaction helper, see chaindp_compact.hip
 	uint8_t *flags;
 	int min_sc;
@@ -486,9 +489,9 @@ __device__ __forceinline__ bool apply_chunk(const UnitCtx &c, const Pairs &P, in
 		wave_mem_fence();
 		tj = c.s_t[j & MASK];
 	} else {
-		if (__builtin_amdgcn_inverse_ballot_w64(P.ok) && P.pj >= 0) c.tg[c.base + P.pj] = tag;
+		if (__builtin_amdgcn_inverse_ballot_w64(P.ok) && P.pj >= 0) c.tg[c.base + P.pj] = c.tg_hi | (uint32_t)tag;
 		wave_global_fence();
-		if (kb0 + lane < i) tj = c.tg[c.base + j];
+		if (kb0 + lane < i && c.tg[c.base + j] == (c.tg_hi | (uint32_t)tag)) tj = tag;
 	}
 	// new running max? strictly greater than everything before it (chain.c:274)
 	const int incl = wave_scan_max(P.sc);
@@ -536,7 +539,7 @@ __device__ __forceinline__ void replay_far_marks(const UnitCtx &c, const ulonglo
 {
 	for (int kb0 = 0; kb0 + 64 <= RING && kb0 < i; kb0 += 64) {
 		const Pairs P = eval_general<RING, false>(c, an, ii, qi, span, i, kb0);
-		if (__builtin_amdgcn_inverse_ballot_w64(P.ok) && P.pj >= 0 && P.pj < i - RING) c.tg[c.base + P.pj] = i;
+		if (__builtin_amdgcn_inverse_ballot_w64(P.ok) && P.pj >= 0 && P.pj < i - RING) c.tg[c.base + P.pj] = c.tg_hi | (uint32_t)i;
 	}
 }
 
@@ -616,6 +619,15 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 			wave_mem_fence();
 			if (lane == 0) c.s_v[pend_slot] = vprev;
 			wave_mem_fence();
+		}
+		{
+			bool not_self = false;
+			if (lane < cnt) {
+				const int my_slot = (tile0 + lane) & MASK;
+				not_self = !(c.s_v[my_slot] >= c.min_sc || (int)c.s_w[4 * my_slot + 3] >= 0);
+				if (not_self) c.first_child[gi] = NO_CHILD;                // see run_unit_fast
+			}
+			if (__builtin_amdgcn_ballot_w64(not_self)) wave_global_fence();
 		}
 		if (lane < cnt) {
 			const int my_slot = (tile0 + lane) & MASK;
@@ -810,7 +822,7 @@ __device__ __forceinline__ void fast_more_chunks(const UnitCtx &c, const FastK &
 				for (int kr = 0; kr < RING; kr += 64) {
 					const FastPairs P = fast_filters<RING, SAMEGAP>(k, ((uint32_t)((i - 1 - kr) << 4) - k.L4) & (L::RB - 1u), xm1, qm1);
 					const int pj4 = (int)P.e.w;
-					if (P.ok && pj4 >= 0 && pj4 < lo4) c.tg[c.base + (pj4 >> 2)] = i;
+					if (P.ok && pj4 >= 0 && pj4 < lo4) c.tg[c.base + (pj4 >> 2)] = c.tg_hi | (uint32_t)i;
 				}
 			}
 			const Pairs P = eval_general<RING, true>(c, an, ii, (int)qm1, spm1 + 1, i, kb0);
@@ -955,6 +967,11 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 			wave_mem_fence();
 			if (lane < cnt) lds_store_b32(L::V_OFF + (waddr >> 2), val);
 			wave_mem_fence();
+			// first_child[] of an anchor that is not emitted at its own step starts at "none" here, before any child (this
+			// tile or a later one, always this wave) lowers it: no batch-wide initialisation pass
+			const bool self = val >= c.min_sc || pi >= 0;
+			if (lane < cnt && !self) c.first_child[gi] = NO_CHILD;
+			if (__builtin_amdgcn_ballot_w64(lane < cnt && !self)) wave_global_fence();
 			if (lane < cnt) {
 				c.f[gi] = fi;
 				c.p[gi] = pi < 0 ? -1 : pi + c.rel0;
@@ -970,7 +987,7 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 					} else { vq = c.v[c.base + pi]; pq = c.p[c.base + pi]; }
 					if (!(vq >= c.min_sc || pq >= 0)) { atomicMin(&c.first_child[c.base + pi], c.rel0 + tile0 + lane); maybe_first = 4; }
 				}
-				c.flags[gi] = (uint8_t)(((val >= c.min_sc || pi >= 0) ? 2 : 0) | maybe_first);
+				c.flags[gi] = (uint8_t)((self ? 2 : 0) | maybe_first);
 			}
 		}
 		if (cnt < 64) break;
@@ -984,13 +1001,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                     const uint16_t *__restrict__ lut, int lut_stride,
                                                     const Unit *__restrict__ units,
                                                     const unsigned long long *__restrict__ counters,
-                                                    int32_t *f, int32_t *p, int32_t *v, int32_t *tg,
+                                                    int32_t *f, int32_t *p, int32_t *v, unsigned long long *tg, uint32_t epoch,
                                                     int32_t *first_child, uint8_t *flags)
 {
 	static_assert((RING & (RING - 1)) == 0 && RING >= 128, "RING must be a power of two >= 128");
 	extern __shared__ uint4 smem[];
 	UnitCtx c;
-	c.a = a; c.f = f; c.p = p; c.v = v; c.tg = tg; c.first_child = first_child; c.flags = flags; c.min_sc = par.min_sc;
+	c.a = a; c.f = f; c.p = p; c.v = v; c.tg = tg; c.tg_hi = (unsigned long long)epoch << 32; c.first_child = first_child; c.flags = flags; c.min_sc = par.min_sc;
 	c.s_w = (uint32_t*)smem;
 	c.s_t = (int*)(c.s_w + 4 * RING);
 	c.s_v = c.s_t + RING;
@@ -1041,17 +1058,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
 hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off, const void *d_a,
                           unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
-                          int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg, int32_t *d_first_child, uint8_t *d_flags)
+                          int32_t *d_f, int32_t *d_p, int32_t *d_v, uint8_t *d_flags)
 {
 	hipError_t e = hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st);
 	if (e != hipSuccess || n_reads <= 0 || total <= 0) return e;
 	if ((e = hipMemsetAsync(d_sumq, 0, (size_t)n_reads * sizeof(unsigned long long), st)) != hipSuccess) return e;
-	if ((e = hipMemsetAsync(d_first_child, 0x7f, (size_t)total * 4, st)) != hipSuccess) return e;   // "no child" (chaindp_compact.hip)
 	const int64_t blocks = (total + PRE_PER_BLOCK - 1) / PRE_PER_BLOCK;
 	const int64_t words = (total + 63) / 64;
 	hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, st, n_reads, total, d_off, sc.block_reads);
 	hipLaunchKernelGGL(k_prepass, dim3((unsigned)blocks), dim3(PRE_BLOCK), 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a,
-	                   d_sumq, sc.start_mask, sc.block_cnt, d_f, d_p, d_v, d_tg, d_flags, sc.block_reads);
+	                   d_sumq, sc.start_mask, sc.block_cnt, d_f, d_p, d_v, d_flags, sc.block_reads);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, d_counters)) != hipSuccess) return e;
 	if ((e = hipMemsetAsync(sc.hist, 0, 2 * UNIT_CLASSES * sizeof(unsigned int), st)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_emit_units, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, n_reads, words, d_off,
@@ -1087,7 +1103,7 @@ hipError_t launch_lut(hipStream_t st, const Params &par, int64_t n_reads, const 
 hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
                         const int32_t *d_n_segs, const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
                         const Unit *d_units, const unsigned long long *d_counters,
-                        int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_tg, int32_t *d_first_child, uint8_t *d_flags)
+                        int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags)
 {
 	if (max_units <= 0) return hipSuccess;
 	// The number of units is only known on the device (counters[0]); the grid is sized for the upper
@@ -1107,9 +1123,9 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
 		if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
 	}
 	switch (ring) {
-	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, d_first_child, d_flags); break;
-	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, d_first_child, d_flags); break;
-	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, d_first_child, d_flags); break;
+	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags); break;
+	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags); break;
+	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags); break;
 	}
 	return hipGetLastError();
 }
