@@ -175,20 +175,40 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_rea
 	const int64_t rlo = rr.x, rhi = rr.y;
 	const bool one_read = rlo == rhi;
 	unsigned int w_sum = 0, w_units = 0, w_singles = 0;
-	for (int64_t gb = g0; gb < g1; gb += PRE_BLOCK) {
+	// all loads of the block's four passes are issued before the first is used (one anchor per thread and pass would
+	// leave a single 16-byte load in flight per thread); neighbours come from the adjacent lanes, and from memory
+	// only at the two ends of a wave's 64 anchors
+	constexpr int PASSES = PRE_PER_BLOCK / PRE_BLOCK;
+	ulonglong2 an_[PASSES];
+	uint64_t xb_[PASSES], xe_[PASSES];
+#pragma unroll
+	for (int k = 0; k < PASSES; ++k) {
+		const int64_t g = g0 + (int64_t)k * PRE_BLOCK + threadIdx.x;
+		an_[k] = make_ulonglong2(0, 0); xb_[k] = 0; xe_[k] = 0;
+		if (g < g1) an_[k] = a[g];
+		if (g < g1 && lane == 0 && g > 0) xb_[k] = a[g - 1].x;
+		if (g < g1 && (lane == 63 || g + 1 == g1) && g + 1 < total) xe_[k] = a[g + 1].x;
+	}
+#pragma unroll
+	for (int k = 0; k < PASSES; ++k) {
+		const int64_t gb = g0 + (int64_t)k * PRE_BLOCK;
+		if (gb >= g1) break;
 		const int64_t g = gb + threadIdx.x;
 		const bool have = g < g1;
+		const ulonglong2 an = an_[k];
+		uint64_t xprev = (uint64_t)__shfl_up((unsigned long long)an.x, 1, 64), xnext = (uint64_t)__shfl_down((unsigned long long)an.x, 1, 64);
+		if (lane == 0) xprev = xb_[k];
+		if (lane == 63 || g + 1 == g1) xnext = xe_[k];
 		bool start = false, single = false;
 		int span = 0;
 		int64_t r = rlo;
 		if (have) {
 			if (!one_read) r = read_of(off, rlo, rhi, g);
 			const int64_t rs = off[r], re = off[r + 1];
-			const ulonglong2 an = a[g];
 			span = span_of_hi((uint32_t)(an.y >> 32));
 			if (seg_of_hi((uint32_t)(an.y >> 32)) != 0) atomicOr(&sumq[r], SUMQ_SEG_FLAG);   // rare: multi-segment reads only
-			start = g == rs || an.x - a[g - 1].x > maxx;
-			const bool next_starts = g + 1 >= re || a[g + 1].x - an.x > maxx;
+			start = g == rs || an.x - xprev > maxx;
+			const bool next_starts = g + 1 >= re || xnext - an.x > maxx;
 			single = start && next_starts;
 			if (single) {                                          // chain.c:251,283-284 with an empty window
 				f[g] = span; p[g] = -1; v[g] = span;
