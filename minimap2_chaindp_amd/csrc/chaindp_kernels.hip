@@ -719,7 +719,8 @@ __device__ __forceinline__ int wave_excl_max_floor0(int v)
 template <int RING>
 struct FastLds {
 	static constexpr uint32_t RB = 16u * RING;            // ring entries
-	static constexpr uint32_t T_OFF = RB;                 // mark tags
+	static constexpr uint32_t T_OFF = 28u * RING;         // mark tags, indexed by distance: word d-1 belongs to anchor i-d (the general
+	                                                      // variant's x.hi/y.hi space); word RING is the dummy word
 	static constexpr uint32_t V_OFF = RB + 4u * RING;     // v
 	static constexpr uint32_t DUMMY = 32u * RING;         // sink for lanes without a mark to write
 	static constexpr uint32_t LUT = 32u * RING + 16u;     // table of 1 - cost (int16)
@@ -727,7 +728,8 @@ struct FastLds {
 
 struct FastK {
 	uint32_t L4;       // lane * 16
-	uint32_t dummy;    // DUMMY - T_OFF, kept opaque so that T_OFF stays in the DS instruction's offset field
+	uint32_t far4;     // 4 * RING: offset of the dummy word behind the mark array (kept in a VGPR for v_cndmask)
+	uint32_t trel;     // 4 * lane: this lane's own mark word in chunk 0
 	uint32_t M;        // max_dist_x
 	uint32_t cbw;      // max(max_dist_x - 1 - bw, 0)
 	uint32_t dq_off;   // max_dist_x - min(max_dist_x, max_dist_y)
@@ -759,7 +761,7 @@ __device__ __forceinline__ FastPairs fast_filters(const FastK &k, uint32_t addr,
 struct FastMasks { uint64_t A, B; int sc; uint32_t drm1; };
 
 template <int RING, bool SAMEGAP>
-__device__ __forceinline__ FastMasks fast_masks(const FastK &k, uint32_t S, uint32_t xm1, uint32_t qm1, int spm1, int i, int lo4, int max_f)
+__device__ __forceinline__ FastMasks fast_masks(const FastK &k, uint32_t S, uint32_t xm1, uint32_t qm1, int spm1, int i, int kb0, int max_f)
 {
 	typedef FastLds<RING> L;
 	const uint32_t addr = (S - k.L4) & (L::RB - 1u);
@@ -770,18 +772,24 @@ __device__ __forceinline__ FastMasks fast_masks(const FastK &k, uint32_t S, uint
 	const uint32_t di = P.dd < k.bw ? P.dd : k.bw;
 	const int scu = sc0 + (int)P.e.z + lds_load_i16(L::LUT + 2u * di);                  // chain.c:272-273 via the table
 	FastMasks m;
-	m.sc = P.ok ? scu : INT_MIN;
+	const uint64_t okm = __builtin_amdgcn_ballot_w64(P.ok);
+	m.sc = __builtin_amdgcn_inverse_ballot_w64(okm) ? scu : INT_MIN;    // (through the mask: two selects on one condition get
+	                                                                    // turned into a divergent branch around the table lookup)
 	m.drm1 = P.drm1;
-	// marks (chain.c:281): lanes without one store into the dummy word instead of being masked off
-	const bool near = P.ok && (int)P.e.w >= lo4;
-	const uint32_t dst = near ? (P.e.w & (4u * RING - 1u)) : k.dummy;
+	// marks (chain.c:281), kept by distance: the mark on p_j goes to word i-1-p_j, lane k of chunk kb0 owns word kb0+k.
+	// No address arithmetic on the reading side, and "older than the ring" is a clamp to the dummy word, where
+	// the lanes without a mark to make store as well (nothing is masked off).  p_j = -1 gives word i, which belongs
+	// to the non-existent anchor -1.
+	const uint32_t d4 = ((uint32_t)(i - 1) << 2) - P.e.w;
+	const uint32_t dcl = d4 < 4u * RING ? d4 : 4u * RING;
+	const uint32_t dst = P.ok ? dcl : k.far4;
 	lds_store_b32(dst + L::T_OFF, i);
 	wave_mem_fence();
-	const int tj = lds_load_b32((addr >> 2) + L::T_OFF);
+	const int tj = lds_load_b32(k.trel + ((uint32_t)kb0 << 2) + L::T_OFF);
 	int excl = wave_excl_max_floor0(m.sc);
 	excl = excl > max_f ? excl : max_f;
 	m.A = __builtin_amdgcn_ballot_w64(m.sc > excl);                                     // masked lanes hold INT_MIN
-	m.B = __builtin_amdgcn_ballot_w64(P.ok) & ~m.A & __builtin_amdgcn_ballot_w64(tj == i);
+	m.B = okm & ~m.A & __builtin_amdgcn_ballot_w64(tj == i);
 	return m;
 }
 
@@ -807,9 +815,9 @@ __device__ __forceinline__ bool fast_walk_general(const FastK &k, const FastMask
 // a further ring chunk (kb0 >= 64); returns true when the scan for anchor i is complete
 template <int RING, bool SAMEGAP>
 __device__ __forceinline__ bool fast_chunk(const FastK &k, uint32_t S, int jtop, uint32_t xm1, uint32_t qm1, int spm1,
-                                           int i, int lo4, int &max_f, int &max_j, int &n_skip)
+                                           int i, int kb0, int &max_f, int &max_j, int &n_skip)
 {
-	const FastMasks m = fast_masks<RING, SAMEGAP>(k, S, xm1, qm1, spm1, i, lo4, max_f);
+	const FastMasks m = fast_masks<RING, SAMEGAP>(k, S, xm1, qm1, spm1, i, kb0, max_f);
 	const int hiA = highest_lane(m.A);
 	if ((m.B & low_mask64(hiA)) == 0) {                            // every A lane precedes every B lane (or one set is empty)
 		if (hiA >= 0) {
@@ -829,13 +837,14 @@ __device__ __forceinline__ bool fast_chunk(const FastK &k, uint32_t S, int jtop,
 // chunks beyond the first for anchor i: ring chunks, then the deep path (predecessors older than the ring, from HBM/L2)
 template <int RING, bool SAMEGAP>
 __device__ __forceinline__ void fast_more_chunks(const UnitCtx &c, const FastK &k, const ulonglong2 &an, int ii, int i, uint32_t xm1, uint32_t qm1,
-                                                 int spm1, int lo4, int &max_f, int &max_j, int &n_skip)
+                                                 int spm1, int &max_f, int &max_j, int &n_skip)
 {
 	typedef FastLds<RING> L;
+	const int lo4 = max((i - RING) << 2, 0);           // 4 * (oldest anchor still in the ring)
 	for (int kb0 = 64; kb0 < i; kb0 += 64) {
 		bool done;
 		if (kb0 + 64 <= RING) {
-			done = fast_chunk<RING, SAMEGAP>(k, (uint32_t)(i - 1 - kb0) << 4, i - 1 - kb0, xm1, qm1, spm1, i, lo4, max_f, max_j, n_skip);
+			done = fast_chunk<RING, SAMEGAP>(k, (uint32_t)(i - 1 - kb0) << 4, i - 1 - kb0, xm1, qm1, spm1, i, kb0, max_f, max_j, n_skip);
 		} else {
 			if (kb0 == RING) {
 				// first deep chunk: marks of the ring chunks whose targets are older than the ring go to the global array now
@@ -864,13 +873,12 @@ __device__ __forceinline__ void fast_anchor_step(const UnitCtx &c, const FastK &
 	                                                   // has landed (a reuse would force a wait right behind the s_load)
 	const int spm1 = span_of_hi(a_cur.w) - 1;
 	off_next = off_next + 16u < off_last ? off_next + 16u : off_last;
-	const int lo4 = max((i - RING) << 2, 0);           // byte offset of the oldest mark slot still in the ring
 	int max_f = spm1 + 1, max_j = -1, n_skip = 0;
 	// chunk 0 (the 64 nearest predecessors) settles most anchors.  It also runs for the unit's first anchors:
 	// slots not written yet fail the window test, so nothing happens on those lanes.  Written out with
 	// explicit exits so that the common path (break inside chunk 0) is straight-line scalar code.
 	{
-		const FastMasks m = fast_masks<RING, SAMEGAP>(k, (uint32_t)(i - 1) << 4, xm1, qm1, spm1, i, lo4, max_f);
+		const FastMasks m = fast_masks<RING, SAMEGAP>(k, (uint32_t)(i - 1) << 4, xm1, qm1, spm1, i, 0, max_f);
 		// next anchor's scalars: issued only now (the address is made to depend on B), after this step's last LDS
 		// wait, so that no LDS wait of this step also waits for the scalar load
 		asm volatile("" : "+s"(off_next) : "s"(m.B));
@@ -886,13 +894,13 @@ __device__ __forceinline__ void fast_anchor_step(const UnitCtx &c, const FastK &
 			n_skip = __builtin_popcountll(m.B);                // n_skip was 0: A lanes cannot lower it
 			if (n_skip > k.ms0) goto anchor_done;              // break taken at a B lane (chain.c:278-279)
 			if ((uint32_t)__builtin_amdgcn_readlane((int)m.drm1, 63) + 1u > k.M) goto anchor_done;   // window exhausted
-			fast_more_chunks<RING, SAMEGAP>(c, k, an, ii, i, xm1, qm1, spm1, lo4, max_f, max_j, n_skip);
+			fast_more_chunks<RING, SAMEGAP>(c, k, an, ii, i, xm1, qm1, spm1, max_f, max_j, n_skip);
 		} else {
 			// A and B lanes interleave (rare): own copy of the tail, so that the common path above shares no
 			// control flow (and no merged exit flags) with it
 			if (fast_walk_general(k, m, i - 1, max_f, max_j, n_skip)) goto anchor_done;
 			if ((uint32_t)__builtin_amdgcn_readlane((int)m.drm1, 63) + 1u > k.M) goto anchor_done;
-			fast_more_chunks<RING, SAMEGAP>(c, k, an, ii, i, xm1, qm1, spm1, lo4, max_f, max_j, n_skip);
+			fast_more_chunks<RING, SAMEGAP>(c, k, an, ii, i, xm1, qm1, spm1, max_f, max_j, n_skip);
 		}
 	}
 anchor_done:
@@ -916,8 +924,10 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 	const int lane = c.lane;
 	FastK k;
 	k.L4 = (uint32_t)lane << 4;
-	k.dummy = L::DUMMY - L::T_OFF;
-	asm volatile("" : "+v"(k.L4), "+v"(k.dummy));           // opaque: keeps (S - 16*lane) & mask at two instructions
+	k.far4 = 4u * RING;
+	k.trel = (uint32_t)lane << 2;
+	asm volatile("" : "+v"(k.L4), "+v"(k.far4), "+v"(k.trel));   // opaque: keeps (S - 16*lane) & mask at two instructions and
+	                                                             // the constant LDS offsets in the DS offset fields
 	k.M = (uint32_t)c.maxx;
 	k.bw = (uint32_t)c.bw;
 	k.cbw = k.M - 1u > k.bw ? k.M - 1u - k.bw : 0u;
@@ -1065,6 +1075,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 			for (int k = lane; k * 8 < lut_stride; k += 64) ((uint4*)s_lut)[k] = src[k];
 			const uint32_t x_none = (uint32_t)a[u.start].x - (uint32_t)c.maxx - 1u;  // "no anchor here yet" (x+1 encoding): fails the window test
 			for (int k = lane; k < RING; k += 64) *(uint4*)(c.s_w + 4 * k) = make_uint4(x_none, 0u, 0u, 0xfffffffcu);
+			for (int k = lane; k < RING; k += 64) ((int*)c.s_yhi)[k] = -1;          // the fast variant's mark words (FastLds::T_OFF)
 		}
 		wave_mem_fence();
 		// u.len bounds the unit (next unit's start or the read's end); run_unit finds the true end at the first gap
