@@ -27,13 +27,31 @@ def _cases(n):
     return out
 
 
+def _fast_cases(n):
+    """Cases the table-driven kernel variant takes (one segment, not cDNA, bw within the table), which is what ordinary
+    long-read input runs on: more of them, with gaps and bandwidths around each other."""
+    rng = np.random.default_rng(20261005)
+    out = []
+    for k in range(n):
+        par = dict(max_dist_x=int(rng.choice([1, 40, 300, 2000, 5000, 10000, 100000])), max_dist_y=int(rng.choice([0, 30, 300, 2000, 5000, 10000, 50000])),
+                   bw=int(rng.choice([0, 7, 100, 500, 2000, 4095])), max_skip=int(rng.choice([-1, 0, 1, 5, 25, 60, 200])),
+                   min_sc=int(rng.choice([0, 15, 40, 100])), is_cdna=0, n_segs=1)
+        gen = dict(read_len=int(rng.choice([200, 1500, 6000])), n_hits=int(rng.integers(1, 25)), min_ovl_pct=int(rng.choice([10, 50, 90])),
+                   step=int(rng.choice([2, 5, 20, 60])), indel_pct=int(rng.choice([0, 30, 80])), indel_max=int(rng.choice([1, 6, 40])),
+                   noise_pct=int(rng.choice([0, 8, 40])), tie_pct=int(rng.choice([0, 2, 30])), q_span=int(rng.choice([1, 15, 28, 200])),
+                   span_jitter=int(rng.choice([0, 9, 55])), n_ref=int(rng.choice([1, 4, 1000])), ref_len=int(rng.choice([3000, 20000])),
+                   n_segs=1)
+        out.append((1000 + k, par, gen, int(rng.choice([128, 128, 256, 512])), False, int(rng.integers(5, 40)), int(rng.choice([1, 2, 3]))))
+    return out
+
+
 @pytest.fixture(scope="module")
 def dev():
     with chaindp.Device(0, max_anchors=1 << 22, max_reads=1 << 12) as d:
         yield d
 
 
-@pytest.mark.parametrize("k,par_kw,gen_kw,ring,general,n_reads,min_cnt", _cases(48))
+@pytest.mark.parametrize("k,par_kw,gen_kw,ring,general,n_reads,min_cnt", _cases(48) + _fast_cases(64))
 def test_random_case(dev, k, par_kw, gen_kw, ring, general, n_reads, min_cnt):
     par = P.ChainParams(**par_kw)
     base = dict(ag.PRESETS["ties"]); base.update(gen_kw)

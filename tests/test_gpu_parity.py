@@ -104,6 +104,56 @@ def test_large_bw_takes_the_general_path(dev):
     assert np.array_equal(f, of) and np.array_equal(p, op) and np.array_equal(v, ov)
 
 
+@pytest.mark.parametrize("par_over", [
+    dict(max_dist_x=10000, max_dist_y=3000),              # query gap below reference gap: saturating-add form of the range test
+    dict(max_dist_x=3000, max_dist_y=10000),              # ... and above it
+    dict(max_dist_x=300, max_dist_y=300, bw=500),         # bw >= max_dist_x: the bandwidth test can never fail on its own
+    dict(max_dist_x=5000, max_dist_y=0),                  # nothing has 1 <= dq <= 0
+    dict(max_dist_x=1, max_dist_y=1, bw=0),
+    dict(max_skip=-1, max_dist_y=700),
+])
+@pytest.mark.parametrize("gen,n_reads", [("dense", 2), ("ties", 40)])
+@pytest.mark.parametrize("ring", [128, 512])
+def test_fast_variant_parameter_corners(dev, par_over, gen, n_reads, ring):
+    """The table-driven variant folds the window, gap and bandwidth tests of chain.c:252-260 into one unsigned compare and keeps
+    marks by distance; 'dense' walks the whole window (ring chunks, far marks, the deep path), 'ties' breaks early."""
+    dev.set_ring(ring)
+    dev.set_variant(False)
+    try:
+        par = P.preset("ava-ont", **par_over)
+        off, a = ag.generate(gen, n_reads=n_reads, seed=77, **(dict(read_len=2500, n_hits=10) if gen == "dense" else {}))
+        f, p, v = dev.chain_batch(par, off, a)
+        of, op, ov, _ = ol.oracle_batch(par, off, a, threads=8)
+        assert np.array_equal(f, of) and np.array_equal(p, op) and np.array_equal(v, ov), (par_over, gen, ring)
+        soff, seeds = dev.compact(par)
+        for r in range(n_reads):
+            lo, hi = int(off[r]), int(off[r + 1])
+            exp = ol.oracle_compact(par, np.ascontiguousarray(a[lo:hi]), of[lo:hi].copy(), op[lo:hi].copy(), ov[lo:hi].copy())
+            assert seeds[int(soff[r]):int(soff[r + 1])].tobytes() == exp.tobytes(), (par_over, gen, r)
+    finally:
+        dev.set_ring(128)
+
+
+def test_reference_position_crossing_2_to_32(dev):
+    """x = rid << 32 | pos is compared as a 64-bit number (chain.c:252); the table-driven variant keeps only x.lo in LDS and
+    relies on modular differences.  A unit whose x.lo wraps around 2^32 must still match."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    x = (np.uint64((1 << 32) - 6000) + np.cumsum(rng.integers(0, 9, n)).astype(np.uint64))
+    assert x[0] < (1 << 32) <= x[-1]
+    q = (np.cumsum(rng.integers(0, 9, n)) + 50).astype(np.uint64)
+    a = np.stack([x, (np.uint64(15) << np.uint64(32)) | q], 1)
+    off = np.array([0, n], np.int64)
+    for ring in (128, 256):
+        dev.set_ring(ring)
+        for preset in ("map-ont", "ava-ont"):
+            par = P.preset(preset)
+            f, p, v = dev.chain_batch(par, off, a)
+            of, op, ov, _ = ol.oracle_fpv(par, a)
+            assert np.array_equal(f, of) and np.array_equal(p, op) and np.array_equal(v, ov), (ring, preset)
+    dev.set_ring(128)
+
+
 def test_edge_batches(dev):
     dev.set_ring(128)
     par = P.preset("map-ont")
