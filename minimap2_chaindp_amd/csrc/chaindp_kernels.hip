@@ -7,18 +7,18 @@
 // How it is computed here (DESIGN.md "Wave formulation"; modelled on the CPU in oracle/wave_model.c):
 //   * k_prepass  -- one thread per anchor: per-read sum of q_span (for avg_qspan, chain.c:240-241);
 //                   split each read into UNITS where a[i].x-a[i-1].x > max_dist_x (independent DP
-//                   problems); resolve single-anchor units on the spot; zero the global mark array.
+//                   problems); resolve single-anchor units on the spot.
 //                   k_emit_units / k_unit_scatter list the units, longest first; k_build_lut tabulates
 //                   the read's gap cost (the reference's f32/f64 arithmetic, once per read and dd).
 //   * k_chain_units -- one wave64 per unit.  Anchors enter in coalesced 64-anchor tiles (16 B per
-//                   lane); the last RING scored anchors live in an LDS ring (16-byte entry x.lo, qpos,
-//                   f, p + mark + v).  For anchor i, lane k evaluates predecessor j = i-1-64c-k of
-//                   chunk c; the serial semantics of the scalar loop are recovered with wave
-//                   primitives: a DPP prefix max for "is this a new running max", lane masks kept as
-//                   64-bit scalars (ballot / inverse_ballot), popcounts (or a DPP prefix min over the
-//                   clamped walk) for n_skip and the break, an LDS scatter for the marks.  A table-driven
-//                   32-bit variant serves ordinary reads, a 64-bit/f64 variant everything else; predecessors
-//                   older than the ring are read back from HBM/L2 (the "deep" path).
+//                   lane); the last RING scored anchors live in an LDS ring.  For anchor i, lane k
+//                   evaluates predecessor j = i-1-64c-k of chunk c; the serial semantics of the scalar
+//                   loop are recovered with wave primitives: a DPP prefix max for "is this a new running
+//                   max", lane masks kept as 64-bit scalars (ballot / inverse_ballot), popcounts (or a DPP
+//                   prefix min over the clamped walk) for n_skip and the break, an LDS scatter for the
+//                   marks.  A table-driven 32-bit variant (run_unit_fast, written for VALU instruction
+//                   count) serves ordinary reads, a 64-bit/f64 variant (run_unit) everything else;
+//                   predecessors older than the ring are read back from HBM/L2 (the "deep" path).
 //   Integer arithmetic only, except the reference's own f32 divide and (int)(dd * .01 * avg_qspan) in f64.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
