@@ -812,12 +812,9 @@ __device__ __forceinline__ bool fast_walk_general(const FastK &k, const FastMask
 	return brk != 0;
 }
 
-// a further ring chunk (kb0 >= 64); returns true when the scan for anchor i is complete
-template <int RING, bool SAMEGAP>
-__device__ __forceinline__ bool fast_chunk(const FastK &k, uint32_t S, int jtop, uint32_t xm1, uint32_t qm1, int spm1,
-                                           int i, int kb0, int &max_f, int &max_j, int &n_skip)
+// n_skip walk over one evaluated chunk (any n_skip on entry); returns true when the break is taken
+__device__ __forceinline__ bool fast_walk(const FastK &k, const FastMasks &m, int jtop, int &max_f, int &max_j, int &n_skip)
 {
-	const FastMasks m = fast_masks<RING, SAMEGAP>(k, S, xm1, qm1, spm1, i, kb0, max_f);
 	const int hiA = highest_lane(m.A);
 	if ((m.B & low_mask64(hiA)) == 0) {                            // every A lane precedes every B lane (or one set is empty)
 		if (hiA >= 0) {
@@ -828,15 +825,67 @@ __device__ __forceinline__ bool fast_chunk(const FastK &k, uint32_t S, int jtop,
 		x = x < 0 ? 0 : x;
 		const int cb = __builtin_popcountll(m.B);
 		n_skip = x + cb;
-		if (cb > 0 && n_skip > k.max_skip) return true;            // break taken at a B lane (chain.c:278-279); n_skip is dead then
-	} else if (fast_walk_general(k, m, jtop, max_f, max_j, n_skip)) return true;
+		return cb > 0 && n_skip > k.max_skip;                      // break taken at a B lane (chain.c:278-279); n_skip is dead then
+	}
+	return fast_walk_general(k, m, jtop, max_f, max_j, n_skip);
+}
+
+// a further ring chunk (kb0 >= 64); returns true when the scan for anchor i is complete
+template <int RING, bool SAMEGAP>
+__device__ __forceinline__ bool fast_chunk(const FastK &k, uint32_t S, int jtop, uint32_t xm1, uint32_t qm1, int spm1,
+                                           int i, int kb0, int &max_f, int &max_j, int &n_skip)
+{
+	const FastMasks m = fast_masks<RING, SAMEGAP>(k, S, xm1, qm1, spm1, i, kb0, max_f);
+	if (fast_walk(k, m, jtop, max_f, max_j, n_skip)) return true;
 	// x sorted => dr grows with the lane: another chunk can only matter if the last lane is inside the window
 	return (uint32_t)__builtin_amdgcn_readlane((int)m.drm1, 63) + 1u > k.M;
 }
 
+// A deep chunk (predecessors older than the ring) of a table-driven unit: the same arithmetic as fast_masks with
+// a[j], f[j], p[j] read back from HBM/L2 and marks in the global array.  Only the window test is done in 64 bits
+// (x_i - x_j of a predecessor this old may exceed 32 bits; for a lane inside the window it does not, and every
+// other difference is bounded by the window).  Returns true when the scan for anchor i is complete.
+template <int RING, bool SAMEGAP>
+__device__ __forceinline__ bool fast_deep_chunk(const UnitCtx &c, const FastK &k, uint64_t xi, uint32_t qi, int spm1, int i, int kb0,
+                                                int &max_f, int &max_j, int &n_skip)
+{
+	typedef FastLds<RING> L;
+	const int j = i - 1 - kb0 - c.lane;
+	const bool inr = j >= 0;
+	const int64_t gj = c.base + (inr ? j : 0);
+	wave_global_fence();                                           // f/p of earlier tiles and the marks written so far
+	const ulonglong2 aj = c.a[gj];
+	const int fj = c.f[gj];
+	const int pjr = c.p[gj];                                       // stored read-relative
+	const bool live = inr && xi - aj.x <= c.maxx;                  // chain.c:252
+	const uint32_t drm1 = (uint32_t)xi - (uint32_t)aj.x - 1u, dqm1 = qi - (uint32_t)aj.y - 1u;
+	const uint32_t dd = absdiff_u32(drm1, dqm1);
+	const uint32_t dqs = SAMEGAP ? dqm1 : __builtin_elementwise_add_sat(dqm1, k.dq_off);
+	const uint32_t m2 = drm1 > dqs ? drm1 : dqs, t = dd + k.cbw;
+	const bool ok = live && (m2 > t ? m2 : t) < k.M;               // chain.c:257-260 (same single compare as fast_filters)
+	int sc0 = (int)dqm1 < (int)drm1 ? (int)dqm1 : (int)drm1;
+	sc0 = sc0 < spm1 ? sc0 : spm1;
+	const uint32_t di = dd < k.bw ? dd : k.bw;
+	const int scu = sc0 + fj + lds_load_i16(L::LUT + 2u * di);
+	FastMasks m;
+	const uint64_t okm = __builtin_amdgcn_ballot_w64(ok);
+	m.sc = __builtin_amdgcn_inverse_ballot_w64(okm) ? scu : INT_MIN;
+	m.drm1 = drm1;
+	const unsigned long long tag = c.tg_hi | (uint32_t)i;
+	if (ok && pjr >= 0) c.tg[c.base + (pjr - c.rel0)] = tag;       // chain.c:281: a predecessor this old has an older one still
+	wave_global_fence();
+	const bool marked = inr && c.tg[gj] == tag;
+	int excl = wave_excl_max_floor0(m.sc);
+	excl = excl > max_f ? excl : max_f;
+	m.A = __builtin_amdgcn_ballot_w64(m.sc > excl);
+	m.B = okm & ~m.A & __builtin_amdgcn_ballot_w64(marked);
+	if (fast_walk(k, m, i - 1 - kb0, max_f, max_j, n_skip)) return true;
+	return __builtin_amdgcn_ballot_w64(live) != ~0ull;             // a lane outside the window (or the unit): nothing older can matter
+}
+
 // chunks beyond the first for anchor i: ring chunks, then the deep path (predecessors older than the ring, from HBM/L2)
 template <int RING, bool SAMEGAP>
-__device__ __forceinline__ void fast_more_chunks(const UnitCtx &c, const FastK &k, const ulonglong2 &an, int ii, int i, uint32_t xm1, uint32_t qm1,
+__device__ __forceinline__ void fast_more_chunks(const UnitCtx &c, const FastK &k, uint32_t xhi, int i, uint32_t xm1, uint32_t qm1,
                                                  int spm1, int &max_f, int &max_j, int &n_skip)
 {
 	typedef FastLds<RING> L;
@@ -854,8 +903,7 @@ __device__ __forceinline__ void fast_more_chunks(const UnitCtx &c, const FastK &
 					if (P.ok && pj4 >= 0 && pj4 < lo4) c.tg[c.base + (pj4 >> 2)] = c.tg_hi | (uint32_t)i;
 				}
 			}
-			const Pairs P = eval_general<RING, true>(c, an, ii, (int)qm1, spm1 + 1, i, kb0);
-			done = apply_chunk<RING, true>(c, P, i, kb0, max_f, max_j, n_skip);
+			done = fast_deep_chunk<RING, SAMEGAP>(c, k, (uint64_t)xhi << 32 | xm1, qm1, spm1, i, kb0, max_f, max_j, n_skip);
 		}
 		if (done) break;
 	}
@@ -894,13 +942,13 @@ __device__ __forceinline__ void fast_anchor_step(const UnitCtx &c, const FastK &
 			n_skip = __builtin_popcountll(m.B);                // n_skip was 0: A lanes cannot lower it
 			if (n_skip > k.ms0) goto anchor_done;              // break taken at a B lane (chain.c:278-279)
 			if ((uint32_t)__builtin_amdgcn_readlane((int)m.drm1, 63) + 1u > k.M) goto anchor_done;   // window exhausted
-			fast_more_chunks<RING, SAMEGAP>(c, k, an, ii, i, xm1, qm1, spm1, max_f, max_j, n_skip);
+			fast_more_chunks<RING, SAMEGAP>(c, k, a_cur.y, i, xm1, qm1, spm1, max_f, max_j, n_skip);
 		} else {
 			// A and B lanes interleave (rare): own copy of the tail, so that the common path above shares no
 			// control flow (and no merged exit flags) with it
 			if (fast_walk_general(k, m, i - 1, max_f, max_j, n_skip)) goto anchor_done;
 			if ((uint32_t)__builtin_amdgcn_readlane((int)m.drm1, 63) + 1u > k.M) goto anchor_done;
-			fast_more_chunks<RING, SAMEGAP>(c, k, an, ii, i, xm1, qm1, spm1, max_f, max_j, n_skip);
+			fast_more_chunks<RING, SAMEGAP>(c, k, a_cur.y, i, xm1, qm1, spm1, max_f, max_j, n_skip);
 		}
 	}
 anchor_done:
