@@ -110,7 +110,8 @@ hipError_t launch_scan_u64(hipStream_t st, int64_t n, unsigned long long *d_data
 
 // C1 happens inside the DP kernel's tile flush (k_chain_units) and the prepass (singletons): they set bit1 of
 // flags[] ("emitted at its own step"), bit2 ("my predecessor is not emitted at its own step, so I may be its first
-// child") and feed first_child[] with atomicMin for exactly those predecessors.
+// child"), bits 3-4 (v >= min_sc, f < v: the record's own flag bits) and feed first_child[] with atomicMin for exactly
+// those predecessors.
 // C2: late bit and per-block record counts.  Only anchors with bit2 look at p[] and first_child[]; for everything
 // else this pass reads one byte per anchor.  One wave per 1024-anchor block, 16 consecutive anchors per lane (one
 // 16-byte load in flight per lane; a 256-thread block per 1024 anchors was bound by its own start-up latency).
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_write_seeds(Params par, int64_t n
 		const int64_t r = rlo == rhi ? rlo : read_of_c(off, rlo, rhi, g);
 		const int64_t rs = off[r];
 		const int32_t so = (int32_t)seeds_off[r];
-		const int32_t q = p[g], vk = v[g], fk = f[g], idk = id[g];
+		const int32_t q = p[g], fk = f[g], idk = id[g];
 		int32_t pfield = (int32_t)(0xfffffffcu);                                             // (-1)<<2
 		if (q >= 0) {
 			if (fl & 1) {                                                                    // late emission of q, chain.c:292-302
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_write_seeds(Params par, int64_t n
 		const ulonglong2 ak = a[g];
 		SeedRec rec;
 		rec.x = ak.x; rec.y = ak.y; rec.f = fk;
-		rec.p = pfield | (int32_t)(vk >= min_sc) | ((int32_t)(fk < vk) << 1);                // chain.c:313-314
+		rec.p = pfield | ((fl >> 3) & 3);                                                    // chain.c:313-314: (v >= min_sc) | (f < v) << 1, from the DP kernel
 		seeds[idk] = rec;
 	}
 }

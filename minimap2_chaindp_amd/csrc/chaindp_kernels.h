@@ -56,7 +56,8 @@ hipError_t launch_scan_u64(hipStream_t st, int64_t n, unsigned long long *d_data
 
 // compaction into new_seed[] (reference chain.c:286-317): see chaindp_compact.hip
 struct CompactScratch {
-	uint8_t *flags;                  // per anchor: bit1 "emitted at its own step" (written by the prepass / DP kernel), bit0 late
+	uint8_t *flags;                  // per anchor: bit0 late; written by the prepass / DP kernel: bit1 "emitted at its own step", bit2 "may be a
+	                                 // first child", bits 3-4 the record flag bits (v >= min_sc, f < v)
 	unsigned long long *block_cnt;   // per 1024-anchor block record count; scanned in place
 	unsigned long long *tile_tmp;
 	unsigned long long *n_seeds;     // total records of the batch

@@ -24,337 +24,9 @@
 #include <stdint.h>
 #include <limits.h>
 #include "chaindp_kernels.h"
+#include "chaindp_wave.h"
 
 namespace chaindp {
-
-#define NO_CHILD 0x7f7f7f7f   // first_child[]: larger than any read-relative index in use
-
-// ---------------------------------------------------------------- wave primitives (wave64, DPP)
-
-// dpp_ctrl encodings (gfx9 family): row_shr:n = 0x110+n, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143
-#define DPP_ROW_SHR(n) (0x110 + (n))
-#define DPP_WAVE_SHR1 0x138
-#define DPP_ROW_BCAST15 0x142
-#define DPP_ROW_BCAST31 0x143
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_or_old(int old, int src)
-{
-	return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
-}
-
-// inclusive prefix max over the 64 lanes (lane 0 first)
-__device__ __forceinline__ int wave_scan_max(int v)
-{
-	v = max(v, dpp_or_old<DPP_ROW_SHR(1), 0xf>(INT_MIN, v));
-	v = max(v, dpp_or_old<DPP_ROW_SHR(2), 0xf>(INT_MIN, v));
-	v = max(v, dpp_or_old<DPP_ROW_SHR(4), 0xf>(INT_MIN, v));
-	v = max(v, dpp_or_old<DPP_ROW_SHR(8), 0xf>(INT_MIN, v));
-	v = max(v, dpp_or_old<DPP_ROW_BCAST15, 0xa>(INT_MIN, v));
-	v = max(v, dpp_or_old<DPP_ROW_BCAST31, 0xc>(INT_MIN, v));
-	return v;
-}
-
-// inclusive prefix min
-__device__ __forceinline__ int wave_scan_min(int v)
-{
-	v = min(v, dpp_or_old<DPP_ROW_SHR(1), 0xf>(INT_MAX, v));
-	v = min(v, dpp_or_old<DPP_ROW_SHR(2), 0xf>(INT_MAX, v));
-	v = min(v, dpp_or_old<DPP_ROW_SHR(4), 0xf>(INT_MAX, v));
-	v = min(v, dpp_or_old<DPP_ROW_SHR(8), 0xf>(INT_MAX, v));
-	v = min(v, dpp_or_old<DPP_ROW_BCAST15, 0xa>(INT_MAX, v));
-	v = min(v, dpp_or_old<DPP_ROW_BCAST31, 0xc>(INT_MAX, v));
-	return v;
-}
-
-// value of lane-1 (lane 0 receives `first`)
-__device__ __forceinline__ int wave_shift_up1(int v, int first)
-{
-	return dpp_or_old<DPP_WAVE_SHR1, 0xf>(first, v);
-}
-
-// number of set bits of the wave-uniform mask m strictly below this lane
-__device__ __forceinline__ int lanes_below(uint64_t m)
-{
-	return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l)
-{
-	uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-	uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
-	return (uint64_t)hi << 32 | lo;
-}
-
-// Orders this wave's LDS/global accesses as seen by its own lanes.  Lanes of one wave hand data to
-// each other through memory (lane 0 stores f[i], every lane reads it one step later); the hardware
-// executes a wave's DS (and, per address space, VMEM) operations in issue order, so all that is needed
-// is that the compiler keeps program order: a wavefront-scope fence emits no instruction.
-__device__ __forceinline__ void wave_mem_fence()
-{
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Same for the deep path, where the hand-off goes through global memory: the stores must have
-// reached the CU's L1/L2 before the loads that follow are issued.  All traffic is from ONE wave on
-// ONE CU, whose vector L1 is coherent for its own work-group, so work-group scope (s_waitcnt vmcnt(0))
-// is sufficient; no agent-scope cache maintenance is involved.
-__device__ __forceinline__ void wave_global_fence()
-{
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// ---------------------------------------------------------------- field access (mmpriv.h:21-22, chain.c:250)
-
-// sumq[r] holds the read's q_span sum (< 2^40); its top bit records "some anchor of the read carries a
-// non-zero segment id", which sends the read's units to the general variant of the DP kernel.
-#define SUMQ_SEG_FLAG (1ull << 63)
-
-__device__ __forceinline__ int span_of_hi(uint32_t yhi) { return (int)(yhi & 0xffu); }        // (y>>32)&0xff
-__device__ __forceinline__ int seg_of_hi(uint32_t yhi) { return (int)((yhi >> 16) & 0xffu); } // (y>>48)&0xff
-
-// ---------------------------------------------------------------- K0: prepass (anchor-parallel, no hot atomics)
-// k_prepass:    one thread per anchor, PRE_PER_BLOCK consecutive anchors of the batch per block.  The
-//               block finds the reads its range touches by binary search in off[]; each thread derives
-//               its unit-start flag and whether it is a singleton (resolved on the spot), zeroes its
-//               global mark, and the block writes: a 64-bit unit-start mask per wave-tile, its unit and
-//               singleton counts, and ONE integer atomic per (block, read) for the q_span sum
-//               (order-independent, so deterministic).
-// launch_scan_u64: exclusive scan of the per-block (units | singletons << 32) counts -> counters[0].
-// k_emit_units: one thread per mask word; writes the Unit records in anchor order (deterministic).
-// A single same-address atomic per wave would cap this stage at ~90 atomics/us (measured: 9 ms for
-// 76 M anchors), hence count -> scan -> emit.
-
-#define PRE_BLOCK 256
-#define PRE_PER_BLOCK CHAINDP_BLOCK_ANCHORS
-#define PRE_WORDS (PRE_PER_BLOCK / 64)
-
-// largest r in [lo, hi] with off[r] <= g   (off is non-decreasing; empty reads are skipped over)
-__device__ __forceinline__ int64_t read_of(const int64_t *__restrict__ off, int64_t lo, int64_t hi, int64_t g)
-{
-	while (lo < hi) {
-		const int64_t mid = (lo + hi + 1) >> 1;
-		if (off[mid] <= g) lo = mid; else hi = mid - 1;
-	}
-	return lo;
-}
-
-// Reads that the first and the last anchor of every 1024-anchor block belong to.  The anchor-parallel kernels
-// of the prepass and of the compaction all cut the batch into the same blocks; a per-block binary search by one
-// thread (28 dependent loads before the block can start) was most of their run time.
-__global__ __launch_bounds__(256) void k_block_reads(int64_t n_reads, int64_t total, const int64_t *__restrict__ off, int2 *__restrict__ block_reads)
-{
-	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const int64_t g0 = b * PRE_PER_BLOCK;
-	if (g0 >= total) return;
-	const int64_t g1 = g0 + PRE_PER_BLOCK < total ? g0 + PRE_PER_BLOCK : total;
-	const int64_t rlo = read_of(off, 0, n_reads - 1, g0);
-	block_reads[b] = make_int2((int)rlo, (int)read_of(off, rlo, n_reads - 1, g1 - 1));
-}
-
-__global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_reads, int64_t total,
-                                                       const int64_t *__restrict__ off, const ulonglong2 *__restrict__ a,
-                                                       unsigned long long *__restrict__ sumq, uint64_t *__restrict__ start_mask,
-                                                       unsigned long long *__restrict__ block_cnt,
-                                                       int32_t *__restrict__ f, int32_t *__restrict__ p, int32_t *__restrict__ v,
-                                                       uint8_t *__restrict__ flags,
-                                                       const int2 *__restrict__ block_reads)
-{
-	__shared__ unsigned int s_sum, s_units, s_singles;
-	const int lane = threadIdx.x & 63;
-	const uint64_t maxx = (uint64_t)(int64_t)par.max_dist_x;
-	const int64_t g0 = (int64_t)blockIdx.x * PRE_PER_BLOCK;
-	const int64_t g1 = g0 + PRE_PER_BLOCK < total ? g0 + PRE_PER_BLOCK : total;
-	if (threadIdx.x == 0) { s_sum = 0; s_units = 0; s_singles = 0; }
-	__syncthreads();
-	const int2 rr = block_reads[blockIdx.x];                       // reads of the block's first and last anchor (k_block_reads)
-	const int64_t rlo = rr.x, rhi = rr.y;
-	const bool one_read = rlo == rhi;
-	unsigned int w_sum = 0, w_units = 0, w_singles = 0;
-	// all loads of the block's four passes are issued before the first is used (one anchor per thread and pass would
-	// leave a single 16-byte load in flight per thread); neighbours come from the adjacent lanes, and from memory
-	// only at the two ends of a wave's 64 anchors
-	constexpr int PASSES = PRE_PER_BLOCK / PRE_BLOCK;
-	ulonglong2 an_[PASSES];
-	uint64_t xb_[PASSES], xe_[PASSES];
-#pragma unroll
-	for (int k = 0; k < PASSES; ++k) {
-		const int64_t g = g0 + (int64_t)k * PRE_BLOCK + threadIdx.x;
-		an_[k] = make_ulonglong2(0, 0); xb_[k] = 0; xe_[k] = 0;
-		if (g < g1) an_[k] = a[g];
-		if (g < g1 && lane == 0 && g > 0) xb_[k] = a[g - 1].x;
-		if (g < g1 && (lane == 63 || g + 1 == g1) && g + 1 < total) xe_[k] = a[g + 1].x;
-	}
-#pragma unroll
-	for (int k = 0; k < PASSES; ++k) {
-		const int64_t gb = g0 + (int64_t)k * PRE_BLOCK;
-		if (gb >= g1) break;
-		const int64_t g = gb + threadIdx.x;
-		const bool have = g < g1;
-		const ulonglong2 an = an_[k];
-		uint64_t xprev = (uint64_t)__shfl_up((unsigned long long)an.x, 1, 64), xnext = (uint64_t)__shfl_down((unsigned long long)an.x, 1, 64);
-		if (lane == 0) xprev = xb_[k];
-		if (lane == 63 || g + 1 == g1) xnext = xe_[k];
-		bool start = false, single = false;
-		int span = 0;
-		int64_t r = rlo;
-		if (have) {
-			if (!one_read) r = read_of(off, rlo, rhi, g);
-			const int64_t rs = off[r], re = off[r + 1];
-			span = span_of_hi((uint32_t)(an.y >> 32));
-			if (seg_of_hi((uint32_t)(an.y >> 32)) != 0) atomicOr(&sumq[r], SUMQ_SEG_FLAG);   // rare: multi-segment reads only
-			start = g == rs || an.x - xprev > maxx;
-			const bool next_starts = g + 1 >= re || xnext - an.x > maxx;
-			single = start && next_starts;
-			if (single) {                                          // chain.c:251,283-284 with an empty window
-				f[g] = span; p[g] = -1; v[g] = span;
-				flags[g] = (uint8_t)(span >= par.min_sc ? 2 : 0);  // emitted at its own step iff v >= min_sc (chain.c:304)
-			}
-		}
-		// q_span sum (chain.c:240): per block when the block sits inside one read, else per wave when the
-		// wave does, else (the one wave that straddles a read boundary) per lane
-		if (one_read) w_sum += (unsigned int)span;
-		else {
-			const int64_t r_first = (int64_t)readlane_u64((uint64_t)r, 0);
-			if (__builtin_amdgcn_ballot_w64(have && r != r_first) == 0) {
-				int sw = have ? span : 0;
-				for (int d = 32; d; d >>= 1) sw += __shfl_xor(sw, d, 64);
-				if (lane == 0 && sw) atomicAdd(&sumq[r_first], (unsigned long long)sw);
-			} else if (have) atomicAdd(&sumq[r], (unsigned long long)span);
-		}
-		const uint64_t em = __builtin_amdgcn_ballot_w64(start && !single);
-		const uint64_t sm = __builtin_amdgcn_ballot_w64(single);
-		if (lane == 0 && gb + (threadIdx.x & ~63) < g1) start_mask[(gb + (threadIdx.x & ~63)) >> 6] = em;
-		w_units += (unsigned int)__builtin_popcountll(em);
-		w_singles += (unsigned int)__builtin_popcountll(sm);
-	}
-	if (one_read) {
-		for (int d = 32; d; d >>= 1) w_sum += __shfl_xor(w_sum, d, 64);
-		if (lane == 0 && w_sum) atomicAdd(&s_sum, w_sum);
-	}
-	if (lane == 0) { atomicAdd(&s_units, w_units); atomicAdd(&s_singles, w_singles); }
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		if (one_read && s_sum) atomicAdd(&sumq[rlo], (unsigned long long)s_sum);
-		block_cnt[blockIdx.x] = (unsigned long long)s_singles << 32 | s_units;   // two counters, one scan
-	}
-}
-
-// Units are scheduled longest first (a unit is one wave's serial work, so a long one started last would be the
-// kernel's tail): 128 length classes, class-descending order, order inside a class immaterial.
-#define UNIT_CLASSES 128
-__device__ __forceinline__ int unit_class(int32_t len)
-{
-	if (len < 4096) return len >> 6;                         // 0..63: 64-anchor steps
-	const int c = 64 + (len >> 12);                          // 65..: 4096-anchor steps
-	return c < UNIT_CLASSES ? c : UNIT_CLASSES - 1;
-}
-
-__global__ __launch_bounds__(256) void k_emit_units(int64_t n_reads, int64_t n_words, const int64_t *__restrict__ off,
-                                                    const uint64_t *__restrict__ start_mask,
-                                                    const unsigned long long *__restrict__ block_base, Unit *__restrict__ units,
-                                                    unsigned int *__restrict__ hist)
-{
-	__shared__ unsigned int s_hist[UNIT_CLASSES];
-	if (threadIdx.x < UNIT_CLASSES) s_hist[threadIdx.x] = 0;
-	__syncthreads();
-	const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	uint64_t m = w < n_words ? start_mask[w] : 0;
-	if (m) {
-		const int64_t b = w / PRE_WORDS;
-		uint64_t pos = (uint32_t)block_base[b];             // low word: units before this block
-		for (int64_t k = b * PRE_WORDS; k < w; ++k) pos += (uint64_t)__builtin_popcountll(start_mask[k]);
-		int64_t r = read_of(off, 0, n_reads - 1, w << 6);
-		while (m) {
-			const int bit = __builtin_ctzll(m);
-			m &= m - 1;
-			const int64_t g = (w << 6) + bit;
-			while (g >= off[r + 1]) ++r;                    // units of one word are in anchor order; reads only move forward
-			const int64_t re = off[r + 1];
-			// upper bound of the unit: the next unit's start or the end of the read (singletons in between are
-			// not units, so this can overshoot the true end; the DP kernel finds the true end itself)
-			int64_t next = -1;
-			if (m) next = (w << 6) + __builtin_ctzll(m);
-			else for (int64_t k = w + 1; k < n_words && (k << 6) < re; ++k) {
-				const uint64_t mm = start_mask[k];
-				if (mm) { next = (k << 6) + __builtin_ctzll(mm); break; }
-			}
-			const int64_t end = next >= 0 && next < re ? next : re;
-			Unit u;
-			u.start = g; u.read = (int32_t)r; u.len = (int32_t)(end - g);
-			units[pos++] = u;
-			atomicAdd(&s_hist[unit_class(u.len)], 1u);
-		}
-	}
-	__syncthreads();
-	if (threadIdx.x < UNIT_CLASSES && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
-}
-
-// hist[c] -> first position of class c in the longest-first order; cursor[c] = 0
-__global__ void k_unit_bases(unsigned int *__restrict__ hist, unsigned int *__restrict__ cursor)
-{
-	if (threadIdx.x == 0) {
-		unsigned int acc = 0;
-		for (int c = UNIT_CLASSES - 1; c >= 0; --c) { const unsigned int n = hist[c]; hist[c] = acc; acc += n; cursor[c] = 0; }
-	}
-}
-
-// scatter into class order: ranks inside a block come from LDS atomics, one global atomic per (block, class)
-// reserves the block's range (a global atomic per wave and class on the handful of hot classes cost 0.45 ms)
-#define SCAT_PER_THREAD 4
-__global__ __launch_bounds__(256) void k_unit_scatter(const unsigned long long *__restrict__ counters, const Unit *__restrict__ in,
-                                                      const unsigned int *__restrict__ base, unsigned int *__restrict__ cursor,
-                                                      Unit *__restrict__ out)
-{
-	__shared__ unsigned int s_cnt[UNIT_CLASSES], s_base[UNIT_CLASSES];
-	const int64_t n = (int64_t)(uint32_t)counters[0];
-	const int64_t per_block = 256 * SCAT_PER_THREAD;
-	for (int64_t b0 = (int64_t)blockIdx.x * per_block; b0 < n; b0 += (int64_t)gridDim.x * per_block) {
-		if (threadIdx.x < UNIT_CLASSES) s_cnt[threadIdx.x] = 0;
-		__syncthreads();
-		Unit u[SCAT_PER_THREAD];
-		int cls[SCAT_PER_THREAD];
-		unsigned int rank[SCAT_PER_THREAD];
-		for (int k = 0; k < SCAT_PER_THREAD; ++k) {
-			const int64_t i = b0 + k * 256 + threadIdx.x;
-			cls[k] = -1;
-			if (i < n) { u[k] = in[i]; cls[k] = unit_class(u[k].len); rank[k] = atomicAdd(&s_cnt[cls[k]], 1u); }
-		}
-		__syncthreads();
-		if (threadIdx.x < UNIT_CLASSES && s_cnt[threadIdx.x])
-			s_base[threadIdx.x] = base[threadIdx.x] + atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]);
-		__syncthreads();
-		for (int k = 0; k < SCAT_PER_THREAD; ++k) if (cls[k] >= 0) out[s_base[cls[k]] + rank[k]] = u[k];
-		__syncthreads();
-	}
-}
-
-// ---------------------------------------------------------------- K0b: per-read gap-cost table
-// For a pair of anchors of the same segment in a non-cDNA run the gap cost depends only on
-// dd = |dr - dq| <= bw and on the read's avg_qspan (chain.c:264,272):
-//     cost(dd) = (int)(dd * .01 * avg_qspan) + (ilog2(dd) >> 1)
-// so it is tabulated once per read (bw+1 entries, uint16) with exactly the
-// reference's f32/f64 operations, and the hot loop does an LDS lookup instead of f64 arithmetic.
-__global__ __launch_bounds__(256) void k_build_lut(Params par, int64_t n_reads, const int64_t *__restrict__ off,
-                                                   const unsigned long long *__restrict__ sumq, int lut_stride,
-                                                   uint16_t *__restrict__ lut)
-{
-	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
-		const int64_t n = off[r + 1] - off[r];
-		if (n <= 0) continue;
-		const float avg = (float)(uint64_t)(sumq[r] & ~SUMQ_SEG_FLAG) / (float)n;   // chain.c:241
-		const double avgd = (double)avg;
-		for (int dd = threadIdx.x; dd <= par.bw; dd += blockDim.x) {
-			const int lg = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
-			const int lin = (int)((double)dd * .01 * avgd);
-			lut[r * lut_stride + dd] = (uint16_t)(int16_t)(1 - (lin + (lg >> 1)));  // stored as 1 - cost (see fast_masks): |.| < 2^15 for bw <= 4095, q_span <= 255
-		}
-	}
-}
 
 // ---------------------------------------------------------------- K1: chain DP, one wave per unit
 
@@ -369,13 +41,6 @@ __device__ __forceinline__ int pair_score(int sc0, int dd, int dr, int dq, bool 
 		return sc0 - (lin + (lg >> 1));
 	}
 	return sc0 - (lin + (lg >> 1));
-}
-
-__device__ __forceinline__ uint32_t absdiff_u32(uint32_t x, uint32_t y)
-{
-	uint32_t d;
-	asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(x), "v"(y));
-	return d;
 }
 
 // Per-unit constants and the LDS carve-up.  Ring entry k (16 B): x.lo, qpos, f, p (unit-relative);
@@ -463,35 +128,10 @@ __device__ __forceinline__ Pairs eval_general(const UnitCtx &c, const ulonglong2
 	return P;
 }
 
-// (1 << n) - 1 for n in [0, 63] as one scalar instruction
-__device__ __forceinline__ uint64_t low_mask64(int n)
-{
-	uint64_t m;
-	asm("s_bfm_b64 %0, %1, 0" : "=s"(m) : "s"(n));
-	return m;
-}
-
 // Applies the serial semantics of chain.c:274-281 to one evaluated chunk.  Marks whose target is still in the
 // ring go to LDS.  Marks on older targets matter only if the scan later reaches a deep chunk; ring chunks do
 // not write them (replay_far_marks does, on demand); deep chunks write all of theirs to the global array.
 // Returns true when the scan for anchor i is complete (break taken, or window / unit exhausted).
-// highest set bit of a 64-bit lane mask; -64 for an empty mask (s_flbit_i32_b64 returns -1), which still gives an
-// empty s_bfm_b64 mask because only the low 6 bits of the width are used
-__device__ __forceinline__ int highest_lane(uint64_t m)
-{
-	int r;
-	asm("s_flbit_i32_b64 %0, %1" : "=s"(r) : "s"(m));
-	return r ^ 63;
-}
-
-// lowest set bit of a 64-bit lane mask; -1 for an empty mask
-__device__ __forceinline__ int lowest_lane(uint64_t m)
-{
-	int r;
-	asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(m));
-	return r;
-}
-
 template <int RING, bool DEEP>
 __device__ __forceinline__ bool apply_chunk(const UnitCtx &c, const Pairs &P, int i, int kb0, int &max_f, int &max_j, int &n_skip)
 {
@@ -666,7 +306,7 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 				else { vq = c.v[c.base + q]; pq = c.p[c.base + q]; }
 				if (!(vq >= c.min_sc || pq >= 0)) { atomicMin(&c.first_child[c.base + q], c.rel0 + tile0 + lane); maybe_first = 4; }
 			}
-			c.flags[gi] = (uint8_t)(((vi >= c.min_sc || q >= 0) ? 2 : 0) | maybe_first);
+			c.flags[gi] = (uint8_t)(((vi >= c.min_sc || q >= 0) ? 2 : 0) | maybe_first | (vi >= c.min_sc ? 8 : 0) | (fp.x < vi ? 16 : 0));
 		}
 		if (cnt < 64) break;
 	}
@@ -692,6 +332,7 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 //     tile at flush time by pointer doubling over the tile (6 rounds of ds_bpermute), not per anchor.
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef int i32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LDS_PTR(T, a) ((__attribute__((address_space(3))) T*)(a))
 #else
@@ -913,7 +554,7 @@ __device__ __forceinline__ void fast_more_chunks(const UnitCtx &c, const FastK &
 // a_cur holds this anchor's mm128_t as four scalar dwords; a_next receives the next anchor's (scalar load issued here).
 template <int RING, bool SAMEGAP>
 __device__ __forceinline__ void fast_anchor_step(const UnitCtx &c, const FastK &k, const ulonglong2 &an, int tile0, int ii, const u32x4_t &a_cur,
-                                                 u32x4_t &a_next, const char *ap, uint32_t &off_next, uint32_t off_last, uint32_t waddr, uint4 W)
+                                                 u32x4_t &a_next, const char *ap, uint32_t &off_next, uint32_t off_last, uint32_t waddr, u32x2_t xq)
 {
 	const int i = tile0 + ii;                          // unit-relative index of the anchor being scored
 	const uint32_t xm1 = a_cur.x, qm1 = a_cur.z;       // ring entries hold x+1 and q+1
@@ -952,16 +593,15 @@ __device__ __forceinline__ void fast_anchor_step(const UnitCtx &c, const FastK &
 		}
 	}
 anchor_done:
-	// anchor i enters the ring (chain.c:283)
-	W.z = (uint32_t)max_f; W.w = (uint32_t)(max_j << 2);
-	wave_mem_fence();
+	// anchor i enters the ring (chain.c:283): a single-lane store with the exec mask set by hand (no branch in the IR,
+	// so the anchor loop has only wave-uniform control flow; exec is all ones here: 64-thread workgroups, uniform
+	// branches only).  (One v_mov_b64 + ds_write2_b64 instead of two v_mov_b32 + ds_write_b128 measured 1 % slower.)
 	{
-		// single-lane store with the exec mask set by hand: no branch in the IR, so the anchor loop has only
-		// wave-uniform control flow (exec is all ones here: 64-thread workgroups, uniform branches only)
-		u32x4_t w4; w4.x = W.x; w4.y = W.y; w4.z = W.z; w4.w = W.w;
+		u32x4_t w4; w4.x = xq.x; w4.y = xq.y; w4.z = (uint32_t)max_f; w4.w = (uint32_t)(max_j << 2);
+		wave_mem_fence();
 		asm volatile("s_bfm_b64 exec, 1, %0\n\tds_write_b128 %1, %2\n\ts_mov_b64 exec, -1" :: "s"(ii), "v"(waddr), "v"(w4) : "memory");
+		wave_mem_fence();
 	}
-	wave_mem_fence();
 }
 
 template <int RING, bool SAMEGAP>
@@ -1007,18 +647,18 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 		uint32_t off_next = 0;
 		u32x4_t a_cur = *(const u32x4_t*)ap;
 		const uint32_t waddr = (uint32_t)((tile0 + lane) & MASK) << 4;
-		uint4 W;
-		W.x = (uint32_t)an.x + 1u; W.y = (uint32_t)an.y + 1u;
+		u32x2_t xq;                                            // first half of this lane's ring entry: x.lo + 1, qpos + 1
+		xq.x = (uint32_t)an.x + 1u; xq.y = (uint32_t)an.y + 1u;
 		// two steps per trip with the scalar registers swapped, so that the prefetched anchor is used in place (a copy at
 		// the end of the step would need the load to have landed by then)
 		{
 			u32x4_t a_alt;
 			int ii = 0;
 			for (; ii + 2 <= cnt; ii += 2) {
-				fast_anchor_step<RING, SAMEGAP>(c, k, an, tile0, ii, a_cur, a_alt, ap, off_next, off_last, waddr, W);
-				fast_anchor_step<RING, SAMEGAP>(c, k, an, tile0, ii + 1, a_alt, a_cur, ap, off_next, off_last, waddr, W);
+				fast_anchor_step<RING, SAMEGAP>(c, k, an, tile0, ii, a_cur, a_alt, ap, off_next, off_last, waddr, xq);
+				fast_anchor_step<RING, SAMEGAP>(c, k, an, tile0, ii + 1, a_alt, a_cur, ap, off_next, off_last, waddr, xq);
 			}
-			if (ii < cnt) fast_anchor_step<RING, SAMEGAP>(c, k, an, tile0, ii, a_cur, a_alt, ap, off_next, off_last, waddr, W);
+			if (ii < cnt) fast_anchor_step<RING, SAMEGAP>(c, k, an, tile0, ii, a_cur, a_alt, ap, off_next, off_last, waddr, xq);
 		}
 		// tile flush: v (chain.c:284) by pointer doubling, then f/p/v and the compaction helpers
 		{
@@ -1065,7 +705,7 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 					} else { vq = c.v[c.base + pi]; pq = c.p[c.base + pi]; }
 					if (!(vq >= c.min_sc || pq >= 0)) { atomicMin(&c.first_child[c.base + pi], c.rel0 + tile0 + lane); maybe_first = 4; }
 				}
-				c.flags[gi] = (uint8_t)((self ? 2 : 0) | maybe_first);
+				c.flags[gi] = (uint8_t)((self ? 2 : 0) | maybe_first | (val >= c.min_sc ? 8 : 0) | (fi < val ? 16 : 0));   // bits 3,4: the record's flag bits (chain.c:313-314)
 			}
 		}
 		if (cnt < 64) break;
@@ -1135,50 +775,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
 // ---------------------------------------------------------------- launchers
 
-hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off, const void *d_a,
-                          unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
-                          int32_t *d_f, int32_t *d_p, int32_t *d_v, uint8_t *d_flags)
-{
-	hipError_t e = hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st);
-	if (e != hipSuccess || n_reads <= 0 || total <= 0) return e;
-	if ((e = hipMemsetAsync(d_sumq, 0, (size_t)n_reads * sizeof(unsigned long long), st)) != hipSuccess) return e;
-	const int64_t blocks = (total + PRE_PER_BLOCK - 1) / PRE_PER_BLOCK;
-	const int64_t words = (total + 63) / 64;
-	hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, st, n_reads, total, d_off, sc.block_reads);
-	hipLaunchKernelGGL(k_prepass, dim3((unsigned)blocks), dim3(PRE_BLOCK), 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a,
-	                   d_sumq, sc.start_mask, sc.block_cnt, d_f, d_p, d_v, d_flags, sc.block_reads);
-	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, d_counters)) != hipSuccess) return e;
-	if ((e = hipMemsetAsync(sc.hist, 0, 2 * UNIT_CLASSES * sizeof(unsigned int), st)) != hipSuccess) return e;
-	hipLaunchKernelGGL(k_emit_units, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, n_reads, words, d_off,
-	                   sc.start_mask, sc.block_cnt, sc.units_tmp, sc.hist);
-	hipLaunchKernelGGL(k_unit_bases, dim3(1), dim3(64), 0, st, sc.hist, sc.hist + UNIT_CLASSES);
-	hipLaunchKernelGGL(k_unit_scatter, dim3((unsigned)(blocks < 1024 ? (blocks > 0 ? blocks : 1) : 1024)), dim3(256), 0, st, d_counters, sc.units_tmp,
-	                   sc.hist, sc.hist + UNIT_CLASSES, d_units);
-	return hipGetLastError();
-}
-
-size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *blocks_bytes)
-{
-	const size_t words = (size_t)(max_anchors + 63) / 64, blocks = (size_t)(max_anchors + PRE_PER_BLOCK - 1) / PRE_PER_BLOCK;
-	*mask_bytes = (words + 1) * 8;
-	*blocks_bytes = (blocks + 1) * 8;
-	return *mask_bytes + 2 * *blocks_bytes;
-}
-
 size_t chain_lds_bytes(int ring, int lut_stride)
 {
 	return (size_t)ring * 32 + 16 + (size_t)lut_stride * 2;
 }
-
-hipError_t launch_lut(hipStream_t st, const Params &par, int64_t n_reads, const int64_t *d_off,
-                      const unsigned long long *d_sumq, int lut_stride, uint16_t *d_lut)
-{
-	if (n_reads <= 0) return hipSuccess;
-	int64_t blocks = n_reads < 65536 ? n_reads : 65536;
-	hipLaunchKernelGGL(k_build_lut, dim3((unsigned)blocks), dim3(256), 0, st, par, n_reads, d_off, d_sumq, lut_stride, d_lut);
-	return hipGetLastError();
-}
-
 hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
                         const int32_t *d_n_segs, const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
                         const Unit *d_units, const unsigned long long *d_counters,
