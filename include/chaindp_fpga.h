@@ -17,17 +17,19 @@
  *   fpga_exit_block / fpga_set_block  fpga.h:52,54  main.c:608,613   unblock / re-arm the receiver
  *
  * Packet format: reference fpga_chaindp.h:46-87 (64-byte packed headers), assembled at map.c:286-324
- * and parsed at map.c:484-568 (device side) / map.c:918-931 (host side).  One difference, by design
- * (SURVEY 8b "Build's boundary"): the FPGA received MINIMIZERS and looked the seeds up in its own
- * index image; this build keeps seed collection on the host, so task packets carry the read's sorted
- * ANCHORS (what mm_chain_dp_fpga receives, chain.c:218) and say so in the header type:
- *   type == CHAINDP_PKT_ANCHORS : payload of each task = seednum x mm128_t anchors, sorted by x
- *   type == 3 (the reference's minimizer packets): every read is answered with err_flag = 1 and no
- *       payload, the reference's own "device cannot handle it" signal -- the host then recomputes that
+ * and parsed at map.c:484-568 (device side) / map.c:918-931 (host side).  Two task payloads are served
+ * (SURVEY 8b "Build's boundary"):
+ *   type == 3 (the reference's packets, unmodified): payload of each task = seednum x mm128_t MINIMIZERS.  The
+ *       FPGA looked the seeds up in its own index image; here the shim's host threads do (collect_seed_hits,
+ *       map.c:187-236, over the image received through fpga_load_index), and the sorted anchors go to the
+ *       GPU.  Without a complete index image every read of such a packet is answered with err_flag = 1 and
+ *       no payload, the reference's own "device cannot handle it" signal -- the host then recomputes that
  *       read on the CPU (map.c:933-944).
+ *   type == CHAINDP_PKT_ANCHORS : payload of each task = seednum x mm128_t anchors, sorted by x (what
+ *       mm_chain_dp_fpga receives, chain.c:218), for hosts that collect seeds themselves.
  * Result packets are exactly the reference's: header echo, then per read collect_result_t +
- * new_seed[n_a] (padded to 64 B) + mini_pos[n_minipos] (padded to 64 B; n_minipos = 0 here because
- * mini_pos is a by-product of seed collection, which the host already has).
+ * new_seed[n_a] (padded to 64 B) + mini_pos[n_minipos] (padded to 64 B) with rep_len; for anchor packets
+ * n_minipos = 0 and rep_len = 0, since those are by-products of seed collection, which that host already has.
  */
 #ifndef CHAINDP_FPGA_H
 #define CHAINDP_FPGA_H
@@ -101,6 +103,16 @@ void chaindp_fpga_configure(int n_gpus, int max_packets_per_batch, unsigned long
 /* Counters since fpga_init: st[0] packets, st[1] reads, st[2] anchors, st[3] device batches,
  * st[4] reads answered err_flag=1. */
 void chaindp_fpga_stats(int64_t st[5]);
+/* The shim's host-side seed collection for minimizer packets (type 3), callable on its own (no GPU involved; tests
+ * and tools): collect_seed_hits of the reference (map.c:187-236) for one read, over the index image received
+ * through fpga_load_index (types 4..7, index.c:603-720) with the flag / max_occ of fpga_set_params (main.c:243).
+ * mini = the read's minimizers as collect_minimizers leaves them (map.c:352), bid / qlen as in collect_task_t.
+ * Writes up to cap_anchors sorted anchors and *n_anchors (the count needed, also when it exceeds the capacity),
+ * *rep_len, and up to n_mini entries of mini_pos with *n_mini_pos.  Returns 0, -1 without a complete index image,
+ * -2 when cap_anchors was too small. */
+int chaindp_fpga_collect_seeds(uint32_t bid, int qlen, const chaindp_anchor_t *mini, int64_t n_mini,
+                               chaindp_anchor_t *anchors, int64_t cap_anchors, int64_t *n_anchors,
+                               int *rep_len, uint64_t *mini_pos, int *n_mini_pos);
 
 #ifdef __cplusplus
 }

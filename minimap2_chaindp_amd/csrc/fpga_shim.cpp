@@ -22,6 +22,7 @@
 #include <unordered_map>
 #include <vector>
 #include "../../include/chaindp_fpga.h"
+#include "seed_collect.h"
 
 static_assert(sizeof(chaindp_pkt_hdr_t) == 64, "chaindp_sndhdr_t must be 64 bytes (reference main.c:296-302)");
 static_assert(sizeof(chaindp_pkt_task_t) == 64, "collect_task_t must be 64 bytes");
@@ -78,6 +79,8 @@ struct Service {
 	unsigned long max_inflight = 1ul << 30;
 	// fpga_set_params (main.c:243)
 	int bw = 500, is_cdna = 0, max_skip = 25, min_sc = 40, flag = 0, max_occ = 0;
+	chaindp::IndexImage index;         // fpga_load_index (main.c:201-204): what the host-side seed collection looks seeds up in
+	int seed_threads = 8;              // host threads a service thread spreads one batch's seed collection over
 	PinnedPool pool;
 	std::mutex mu;
 	std::condition_variable cv_submit, cv_result;
@@ -94,10 +97,14 @@ Service g;
 
 struct ReadRef {
 	const chaindp_pkt_task_t *task;
-	const chaindp_anchor_t *anchors;
+	const chaindp_anchor_t *anchors;   // anchor packets: the payload; minimizer packets: filled in by the seed collection
+	const chaindp_anchor_t *mini;      // minimizer packets (type 3): the payload
+	int64_t n_anchors;
 	int pkt, idx;          // position in the batch's packet list / within the packet
 	bool on_device;        // false: answered with err_flag = 1
 	int64_t batch_read;    // index in the device batch
+	int rep_len;           // minimizer packets: collect_result_t::rep_len / n_minipos and the mini_pos[] payload
+	std::vector<uint64_t> mini_pos;
 };
 
 void fail_hard(const char *what)
@@ -116,7 +123,8 @@ void service_loop(int device)
 	std::vector<ReadRef> reads;
 	for (;;) {
 		pk.clear(); reads.clear();
-		int bw, is_cdna, max_skip, min_sc;
+		int bw, is_cdna, max_skip, min_sc, sflag, max_occ, seed_threads;
+		bool have_index;
 		{
 			std::unique_lock<std::mutex> lk(g.mu);
 			g.cv_submit.wait(lk, [] { return g.stopping || !g.submit_q.empty(); });
@@ -129,6 +137,7 @@ void service_loop(int device)
 				pk.push_back(s); g.submit_q.pop_front();
 			}
 			bw = g.bw; is_cdna = g.is_cdna; max_skip = g.max_skip; min_sc = g.min_sc;
+			sflag = g.flag; max_occ = g.max_occ; have_index = g.index.complete(); seed_threads = g.seed_threads;
 		}
 		// ---- parse (map.c:484-568 walks the packet the same way)
 		for (size_t k = 0; k < pk.size(); ++k) {
@@ -139,12 +148,50 @@ void service_loop(int device)
 				const chaindp_pkt_task_t *t = (const chaindp_pkt_task_t*)q;
 				ReadRef rr;
 				rr.task = t; rr.anchors = (const chaindp_anchor_t*)(q + sizeof(chaindp_pkt_task_t));
+				rr.mini = nullptr; rr.n_anchors = t->seednum > 0 ? t->seednum : 0; rr.rep_len = 0;
 				rr.pkt = (int)k; rr.idx = i; rr.batch_read = -1;
 				rr.on_device = h->type == CHAINDP_PKT_ANCHORS && t->seednum >= 0 && t->gap_ref >= 0 && t->gap_qry >= 0;
+				if (h->type == CHAINDP_PKT_MINIMIZERS && have_index && t->seednum >= 0 && t->gap_ref >= 0 && t->gap_qry >= 0) {
+					rr.mini = rr.anchors; rr.anchors = nullptr; rr.n_anchors = 0;   // seeds are collected below
+					rr.on_device = true;
+				}
 				const uint64_t payload = CHAINDP_ALIGN64((uint64_t)(t->seednum > 0 ? t->seednum : 0) * sizeof(chaindp_anchor_t));
 				q += sizeof(chaindp_pkt_task_t) + payload;
 				if ((size_t)(q - base) > pk[k].size) fail_hard("task packet shorter than its headers claim");
 				reads.push_back(rr);
+			}
+		}
+		// ---- minimizer packets: the reference's device did the seed lookup (map.c:523 inside fpga_work); here the shim's
+		// host threads do, over the index image of fpga_load_index, into one pinned staging buffer per batch
+		void *seed_stage = nullptr;
+		{
+			std::vector<size_t> todo;
+			for (size_t r = 0; r < reads.size(); ++r) if (reads[r].mini) todo.push_back(r);
+			if (!todo.empty()) {
+				std::vector<std::vector<chaindp::U128>> got(todo.size());
+				auto work = [&](size_t t0, size_t step) {
+					for (size_t t = t0; t < todo.size(); t += step) {
+						ReadRef &rr = reads[todo[t]];
+						chaindp::collect_seed_hits(g.index, sflag, max_occ, (const chaindp::U128*)rr.mini, (size_t)rr.task->seednum,
+						                           rr.task->bid, rr.task->qlensum, got[t], &rr.rep_len, rr.mini_pos);
+					}
+				};
+				const size_t nt = std::min<size_t>((size_t)(seed_threads > 1 ? seed_threads : 1), todo.size());
+				std::vector<std::thread> th;
+				for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t, nt);
+				work(0, nt);
+				for (auto &x : th) x.join();
+				size_t tot = 0;
+				for (auto &v : got) tot += v.size();
+				seed_stage = g.pool.get((tot ? tot : 1) * sizeof(chaindp_anchor_t));
+				if (!seed_stage) fail_hard("out of pinned memory");
+				chaindp_anchor_t *dst = (chaindp_anchor_t*)seed_stage;
+				for (size_t t = 0; t < todo.size(); ++t) {
+					ReadRef &rr = reads[todo[t]];
+					if (!got[t].empty()) memcpy(dst, got[t].data(), got[t].size() * sizeof(chaindp_anchor_t));
+					rr.anchors = dst; rr.n_anchors = (int64_t)got[t].size();
+					dst += got[t].size();
+				}
 			}
 		}
 		// ---- group by (gap_ref, gap_qry): one device batch per distinct pair (one pair in practice)
@@ -169,7 +216,8 @@ void service_loop(int device)
 				size_t bytes = sizeof(chaindp_pkt_hdr_t);
 				for (int i = 0; i < (int)h->num; ++i) {
 					bytes += sizeof(chaindp_pkt_result_t);
-					if (reads[r0 + i].on_device) bytes += CHAINDP_ALIGN64((uint64_t)n_a[r0 + i] * sizeof(chaindp_seed_t));
+					if (reads[r0 + i].on_device) bytes += CHAINDP_ALIGN64((uint64_t)n_a[r0 + i] * sizeof(chaindp_seed_t))
+					                                       + CHAINDP_ALIGN64((uint64_t)reads[r0 + i].mini_pos.size() * sizeof(uint64_t));
 				}
 				char *ob = (char*)g.pool.get(bytes);
 				if (!ob) fail_hard("out of pinned memory");
@@ -188,15 +236,22 @@ void service_loop(int device)
 						++n_err;
 					} else {
 						const uint64_t sb = (uint64_t)n_a[r0 + i] * sizeof(chaindp_seed_t), sp = CHAINDP_ALIGN64(sb);
+						const uint64_t mb = (uint64_t)rr.mini_pos.size() * sizeof(uint64_t), mp = CHAINDP_ALIGN64(mb);
 						res->n_a = (uint32_t)n_a[r0 + i];
-						res->sub_size = (uint32_t)(sizeof(chaindp_pkt_result_t) + sp);
+						res->n_minipos = (uint32_t)rr.mini_pos.size(); res->rep_len = rr.rep_len;   // map.c:530-531; zero for anchor packets
+						res->sub_size = (uint32_t)(sizeof(chaindp_pkt_result_t) + sp + mp);
 						seed_dst[r0 + i] = (chaindp_seed_t*)q;
 						if (seed_src[r0 + i]) {
 							if (sb) memcpy(q, seed_src[r0 + i], sb);
 							if (sp > sb) memset(q + sb, 0, sp - sb);
 						}
 						q += sp;
-						n_anchors_done += rr.task->seednum;
+						if (mp) {                                                             // mini_pos[] behind new_seed[] (map.c:547-552)
+							memcpy(q, rr.mini_pos.data(), mb);
+							if (mp > mb) memset(q + mb, 0, mp - mb);
+							q += mp;
+						}
+						n_anchors_done += rr.n_anchors;
 					}
 					++n_reads_done;
 				}
@@ -215,7 +270,7 @@ void service_loop(int device)
 			std::vector<int32_t> nseg(idx.size());
 			for (size_t k = 0; k < idx.size(); ++k) {
 				const ReadRef &rr = reads[idx[k]];
-				off[k + 1] = off[k] + rr.task->seednum;
+				off[k + 1] = off[k] + rr.n_anchors;
 				ptrs[k] = rr.anchors;
 				nseg[k] = rr.task->n_segs;
 			}
@@ -247,6 +302,7 @@ void service_loop(int device)
 		}
 		if (!single_group || groups.empty()) build_packets();
 		for (void *s : group_stage) g.pool.put(s);
+		if (seed_stage) g.pool.put(seed_stage);
 		{
 			std::lock_guard<std::mutex> lk(g.mu);
 			for (size_t k = 0; k < pk.size(); ++k) { g.inflight_bytes -= pk[k].size; g.pool.put(pk[k].buf); }
@@ -298,6 +354,7 @@ extern "C" void fpga_finalize(void)
 {
 	{
 		std::lock_guard<std::mutex> lk(g.mu);
+		g.index.clear();                       // the index image belongs to the session that loaded it
 		if (!g.up) return;
 		g.stopping = true;
 	}
@@ -320,9 +377,35 @@ extern "C" void fpga_set_params(int bw, int is_cdna, int max_skip, int min_sc, i
 
 extern "C" void fpga_load_index(void *addr, int size, int type)
 {
-	// index.c:102-119 streams the B/H/V/P index image (types 4..7) to the FPGA, which did the seed
-	// lookup itself.  Here seed collection stays on the host, so the image is not needed.
-	(void)addr; (void)size; (void)type;
+	// index.c:102-119 streams the B/H/V/P index image (types 4..7) to the FPGA, which did the seed lookup itself.
+	// Here the lookup runs on the shim's host threads (seed_collect.cpp) for packets that still carry minimizers
+	// (type 3, the unmodified reference); anchor packets (type 0x41) do not need the image.
+	if (!addr || size <= 0) return;
+	std::lock_guard<std::mutex> lk(g.mu);
+	g.index.append(type, addr, (size_t)size);
+}
+
+extern "C" int chaindp_fpga_collect_seeds(uint32_t bid, int qlen, const chaindp_anchor_t *mini, int64_t n_mini,
+                                          chaindp_anchor_t *anchors, int64_t cap_anchors, int64_t *n_anchors,
+                                          int *rep_len, uint64_t *mini_pos, int *n_mini_pos)
+{
+	int flag, max_occ;
+	{
+		std::lock_guard<std::mutex> lk(g.mu);
+		if (!g.index.complete()) return -1;
+		flag = g.flag; max_occ = g.max_occ;
+	}
+	std::vector<chaindp::U128> a;
+	std::vector<uint64_t> mp;
+	int rl = 0;
+	chaindp::collect_seed_hits(g.index, flag, max_occ, (const chaindp::U128*)mini, (size_t)(n_mini > 0 ? n_mini : 0), bid, qlen, a, &rl, mp);
+	if (n_anchors) *n_anchors = (int64_t)a.size();
+	if (rep_len) *rep_len = rl;
+	if (n_mini_pos) *n_mini_pos = (int)mp.size();
+	if (mini_pos && !mp.empty()) memcpy(mini_pos, mp.data(), mp.size() * sizeof(uint64_t));
+	if ((int64_t)a.size() > cap_anchors) return -2;
+	if (anchors && !a.empty()) memcpy(anchors, a.data(), a.size() * sizeof(chaindp_anchor_t));
+	return 0;
 }
 
 extern "C" void *fpga_get_writebuf_thread(unsigned long size, int type, int tid)

@@ -1,0 +1,49 @@
+// seed_collect.h -- host-side seed collection for unmodified minimizer packets (reference type 3).
+//
+// The reference's FPGA received minimizers and looked the seeds up itself, in an index image the host streams to
+// it through fpga_load_index (index.c:603-720 builds the image, main.c:201-204 sends it as types 4..7).  SURVEY
+// section 8(b) keeps seed collection on the host in this build: the shim's worker threads run the equivalent of
+// collect_seed_hits (map.c:112-236) over that same image and hand sorted anchors to the GPU.  This is host code
+// of the packet shim, not a CPU path of the chaining DP.
+#ifndef CHAINDP_SEED_COLLECT_H
+#define CHAINDP_SEED_COLLECT_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <vector>
+
+namespace chaindp {
+
+struct U128 { uint64_t x, y; };   // mm128_t (minimap.h:48)
+
+// The four blobs of the image, as written by index.c:603-720:
+//   B: per hash bucket 16 bytes: w0 = (p_off & 0xff) << 56 | n_buckets << 24;  w1 = h_off << 28 | p_off >> 8
+//      (h_off in hash slots, rounded up to 8 per bucket; p_off in entries of P; an empty bucket is all zero)
+//   H: per 8 hash slots 64 bytes: 4 B khash flag word (2 bits per slot, 16 slots), 8 x 6 B keys (low 48 bits), 12 B pad
+//   V: per hash slot 8 bytes: the khash value (a position if the key's bit 0 is set, else p index << 32 | count)
+//   P: 8 bytes per position
+class IndexImage {
+public:
+	void append(int type, const void *data, size_t bytes);   // fpga_load_index chunks, type 4..7 (fpga.h:20-23)
+	bool complete() const { return !B_.empty() && !H_.empty() && !V_.empty(); }
+	void clear();
+	// mm_idx_get (index.c:221-238) over the image: positions of minimizer `minier`, *n of them (0 if absent)
+	const uint64_t *get(uint64_t minier, int *n) const;
+private:
+	void seal();
+	std::vector<uint8_t> B_, H_, V_, P_;
+	int b_bits_ = -1;
+};
+
+// collect_seed_hits (map.c:187-236, with collect_matches map.c:112-146 and skip_seed map.c:148-185): the sorted
+// anchors of one read, its repetitive length and the positions of the minimizers that were used.
+void collect_seed_hits(const IndexImage &idx, int flag, int max_occ, const U128 *mv, size_t mv_n, uint32_t bid, int qlen,
+                       std::vector<U128> &a, int *rep_len, std::vector<uint64_t> &mini_pos);
+
+// radix_sort_128x (ksort.h:101-151 instantiated at misc.c:136): in-place MSD radix sort on x, 8 bits a level,
+// insertion sort below 65 elements.  Unstable; the order of equal keys is part of the result the DP sees, so the
+// procedure is followed step by step.
+void radix_sort_128x(U128 *beg, U128 *end);
+
+} // namespace chaindp
+#endif

@@ -74,18 +74,24 @@ def lib():
         L.chaindp_fpga_configure.argtypes = [C.c_int, C.c_int, C.c_ulong]
         L.chaindp_fpga_stats.restype = None
         L.chaindp_fpga_stats.argtypes = [vp]
+        L.chaindp_fpga_collect_seeds.restype = C.c_int
+        L.chaindp_fpga_collect_seeds.argtypes = [C.c_uint32, C.c_int, vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_int64),
+                                                 C.POINTER(C.c_int), vp, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
 
 def build_task_packet(reads, gap_ref, gap_qry, tid=0, n_segs=1, pkt_type=PKT_ANCHORS, qlensum=0):
-    """reads: list of (read_id, anchors uint64[n,2]).  Layout of package_task (map.c:286-324)."""
+    """reads: list of (read_id, payload uint64[n,2]) or (read_id, payload, bid, qlen): anchors for PKT_ANCHORS, the read's
+    minimizers for PKT_MINIMIZERS (then bid and qlen matter, map.c:350,523).  Layout of package_task (map.c:286-324)."""
     body = bytearray()
-    for read_id, a in reads:
+    for item in reads:
+        read_id, a = item[0], item[1]
+        bid, qlen = (item[2], item[3]) if len(item) > 2 else (0, qlensum)
         a = np.ascontiguousarray(a, np.uint64).reshape(-1, 2)
         t = PktTask()
-        t.gap_qry, t.gap_ref, t.seednum, t.qlensum = gap_qry, gap_ref, a.shape[0], qlensum
-        t.read_id, t.bid, t.n_segs = read_id, 0, n_segs
+        t.gap_qry, t.gap_ref, t.seednum, t.qlensum = gap_qry, gap_ref, a.shape[0], qlen
+        t.read_id, t.bid, t.n_segs = read_id, bid, n_segs
         body += bytes(t)
         raw = a.tobytes()
         body += raw + b"\0" * (_align64(len(raw)) - len(raw))
@@ -114,6 +120,55 @@ def parse_result_packet(buf):
     return out
 
 
+def parse_result_packet_full(buf):
+    """-> list of (read_id, err_flag, new_seed[], mini_pos uint64[], rep_len): parse_result_packet plus the by-products of
+    seed collection that minimizer packets return (map.c:530-531,547-552)."""
+    buf = bytes(buf)
+    h = PktHdr.from_buffer_copy(buf[:64])
+    pos, out = 64, []
+    for _ in range(h.num):
+        r = PktResult.from_buffer_copy(buf[pos:pos + 64])
+        pos += 64
+        if r.err_flag == 1:
+            out.append((r.read_id, 1, None, None, 0))
+            continue
+        nbytes = r.n_a * SEED_DTYPE.itemsize
+        seeds = np.frombuffer(buf, SEED_DTYPE, r.n_a, pos).copy()
+        pos += _align64(nbytes)
+        mini_pos = np.frombuffer(buf, np.uint64, r.n_minipos, pos).copy()
+        pos += _align64(r.n_minipos * 8)
+        out.append((r.read_id, 0, seeds, mini_pos, r.rep_len))
+    return out
+
+
+def load_index(img):
+    """img: the four blobs B, H, V, P of the reference's index image (index.c:603-720), sent as main.c:201-204 does."""
+    L = lib()
+    for k, blob in enumerate(img):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        if blob.size:
+            L.fpga_load_index(blob.ctypes.data, int(blob.size), 4 + k)      # TYPE_INDEX_B.. (fpga.h:20-23)
+
+
+def collect_seeds(bid, qlen, mini):
+    """The shim's host-side collect_seed_hits for one read -> (anchors uint64[n,2], rep_len, mini_pos uint64[])."""
+    L = lib()
+    mini = np.ascontiguousarray(mini, np.uint64).reshape(-1, 2)
+    n, rl, nmp = C.c_int64(0), C.c_int(0), C.c_int(0)
+    mp = np.zeros(len(mini) + 1, np.uint64)
+    cap = 1 << 12
+    while True:
+        out = np.zeros((cap, 2), np.uint64)
+        rc = L.chaindp_fpga_collect_seeds(int(bid), int(qlen), mini.ctypes.data, len(mini), out.ctypes.data, cap,
+                                          C.byref(n), C.byref(rl), mp.ctypes.data, C.byref(nmp))
+        if rc == -2:
+            cap = int(n.value)
+            continue
+        if rc != 0:
+            raise chaindp.ChainDPError("chaindp_fpga_collect_seeds: no complete index image (fpga_load_index types 4..7)")
+        return out[:n.value].copy(), rl.value, mp[:nmp.value].copy()
+
+
 def build_result_packet_for_test(hdr, items):
     """Inverse of parse_result_packet, only used to test the parser without a GPU."""
     body = bytearray()
@@ -137,12 +192,14 @@ class Driver:
     """fpga_init ... fpga_finalize bracket (main.c:511-519,605-615) with a receiver thread that plays
     recv_task_thread (fpga_chaindp.c:228-270): blocks in fpga_get_retbuf, copies the packet, releases it."""
 
-    def __init__(self, bw=500, is_cdna=0, max_skip=25, min_sc=40, n_gpus=0, max_packets_per_batch=64):
+    def __init__(self, bw=500, is_cdna=0, max_skip=25, min_sc=40, n_gpus=0, max_packets_per_batch=64, flag=0, max_occ=0, index=None):
         self.L = lib()
         self.L.chaindp_fpga_configure(n_gpus, max_packets_per_batch, 0)
         if self.L.fpga_init(0) != 0:
             raise chaindp.ChainDPError("fpga_init failed: no GPU (there is no CPU fallback)")
-        self.L.fpga_set_params(bw, is_cdna, max_skip, min_sc, 0, 0)        # main.c:243
+        if index is not None:
+            load_index(index)                                                # main.c:201-204
+        self.L.fpga_set_params(bw, is_cdna, max_skip, min_sc, flag, max_occ)   # main.c:243
         self.results = []
         self._lock = threading.Lock()
         self._rx = threading.Thread(target=self._recv_loop, daemon=True)

@@ -19,6 +19,14 @@
  * Output (little endian): magic "ANCHDMP1", int32 n_reads, then per read:
  *   int32 max_dist_x (gap_ref), int32 max_dist_y (gap_qry), int32 bw, int32 max_skip,
  *   int32 min_sc, int32 is_cdna, int32 n_segs, int32 min_cnt, int64 n, n * mm128_t.
+ *
+ * With a fifth argument it also writes what the reference hands to its device for the seed-collection step
+ * (SURVEY row N2), so that a restatement of collect_seed_hits over the device's index image can be pinned:
+ *   magic "SEEDDMP1"; int32 flag, int32 mid_occ, int32 n_reads; the index image the reference serialises for the
+ *   FPGA (index.c:603-720; what main.c:201-204 sends through fpga_load_index as types 4..7), as four blobs
+ *   (int64 bytes, data) in the order B, H, V, P; then per read: uint32 bid, int32 qlen, int64 n_mini, n_mini * mm128_t
+ *   minimizers (map.c:352), int64 n_a, n_a * mm128_t sorted anchors (collect_seed_hits' result), int32 rep_len,
+ *   int32 n_mini_pos, n_mini_pos * uint64 mini_pos.
  */
 #include "map.c"
 
@@ -30,7 +38,7 @@ int main(int argc, char **argv)
 	mm_idx_t *mi;
 	mm_bseq_file_t *fp;
 	mm_bseq1_t *seqs;
-	FILE *out;
+	FILE *out, *sd = 0;
 	int n_seq = 0, i, n_written = 0;
 	long pos_n;
 
@@ -53,6 +61,19 @@ int main(int argc, char **argv)
 	fwrite("ANCHDMP1", 1, 8, out);
 	pos_n = ftell(out);
 	fwrite(&n_written, 4, 1, out);
+	if (argc > 5) {
+		idx_buf_t *img[4] = { mi->b_idx, mi->h_idx, mi->v_idx, mi->p_idx };
+		int32_t h3[3] = { mo.flag, mo.mid_occ, 0 };
+		int k;
+		sd = fopen(argv[5], "wb");
+		fwrite("SEEDDMP1", 1, 8, sd);
+		fwrite(h3, 4, 3, sd);
+		for (k = 0; k < 4; ++k) {
+			int64_t nb = (int64_t)img[k]->pos;
+			fwrite(&nb, 8, 1, sd);
+			fwrite(img[k]->buf, 1, nb, sd);
+		}
+	}
 
 	for (i = 0; i < n_seq; ++i) {
 		const char *s = seqs[i].seq;
@@ -77,12 +98,21 @@ int main(int argc, char **argv)
 		fwrite(hdr, 4, 8, out);
 		fwrite(&n_a, 8, 1, out);
 		fwrite(a, sizeof(mm128_t), n_a, out);
+		if (sd) {
+			int64_t nm = mv.n;
+			int32_t t2[2] = { rep_len, n_mini_pos };
+			fwrite(&bid, 4, 1, sd); fwrite(&qlen, 4, 1, sd);
+			fwrite(&nm, 8, 1, sd); fwrite(mv.a, sizeof(mm128_t), mv.n, sd);
+			fwrite(&n_a, 8, 1, sd); fwrite(a, sizeof(mm128_t), n_a, sd);
+			fwrite(t2, 4, 2, sd); fwrite(mini_pos, 8, n_mini_pos, sd);
+		}
 		++n_written;
 		free(a); free(mini_pos); kfree(0, mv.a);
 	}
 	fseek(out, pos_n, SEEK_SET);
 	fwrite(&n_written, 4, 1, out);
 	fclose(out);
+	if (sd) { fseek(sd, 16, SEEK_SET); fwrite(&n_written, 4, 1, sd); fclose(sd); }
 	fprintf(stderr, "mt_dump: %d reads written\n", n_written);
 	return 0;
 }

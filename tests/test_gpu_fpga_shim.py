@@ -1,5 +1,7 @@
 """GPU tier: the reference's driver ABI (fpga.h) served by the GPU: anchor packets in, result packets
 out, from several producer threads, checked against the oracle's new_seed[] byte for byte."""
+import glob
+import os
 import threading
 
 import numpy as np
@@ -46,7 +48,7 @@ def test_minimizer_packets_get_err_flag_and_mixed_gaps_are_grouped():
     par = P.preset("map-ont")
     off, a = ag.generate("map-ont", n_reads=6, seed=5, read_len=2000)
     with fpga.Driver(bw=par.bw, is_cdna=0, max_skip=par.max_skip, min_sc=par.min_sc) as drv:
-        # the reference's own packet type (minimizers, type 3): answered with err_flag=1, header only
+        # the reference's own packet type (minimizers, type 3) WITHOUT an index image: answered with err_flag=1, header only
         drv.submit(fpga.build_task_packet([(0, a[off[0]:off[1]])], 5000, 5000, pkt_type=fpga.PKT_MINIMIZERS))
         # two reads with different (gap_ref, gap_qry) in one packet stream
         drv.submit(fpga.build_task_packet([(1, a[off[1]:off[2]])], 5000, 5000))
@@ -63,3 +65,40 @@ def test_minimizer_packets_get_err_flag_and_mixed_gaps_are_grouped():
         ar = np.ascontiguousarray(a[off[rid]:off[rid + 1]])
         f, p, v, _ = ol.oracle_fpv(pr, ar)
         assert got[rid][1].tobytes() == ol.oracle_compact(pr, ar, f, p, v).tobytes()
+
+
+SEED_FIXTURES = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seeds", "*.npz")))
+
+
+@pytest.mark.parametrize("path", SEED_FIXTURES, ids=[os.path.basename(p)[:-4] for p in SEED_FIXTURES])
+def test_unmodified_minimizer_packets_end_to_end(path):
+    """The reference's own packets (type 3, minimizers; map.c:286-324) with its index image loaded through
+    fpga_load_index: seeds are collected by the shim's host threads, chained on the GPU, and every result packet carries
+    what fpga_work (map.c:484-568) would have produced: new_seed[] of the reference's anchors, mini_pos[] and rep_len."""
+    g = np.load(path, allow_pickle=False)
+    pv = [int(x) for x in g["params"]]          # max_dist_x, max_dist_y, bw, max_skip, min_sc, is_cdna, n_segs, min_cnt
+    par = P.ChainParams(max_dist_x=pv[0], max_dist_y=pv[1], bw=pv[2], max_skip=pv[3], min_sc=pv[4], is_cdna=pv[5], n_segs=1)
+    n_reads = len(g["bid"])
+    reads = [(r, g["mini"][g["mini_off"][r]:g["mini_off"][r + 1]], int(g["bid"][r]), int(g["qlen"][r])) for r in range(n_reads)]
+    with fpga.Driver(bw=par.bw, is_cdna=par.is_cdna, max_skip=par.max_skip, min_sc=par.min_sc, flag=int(g["flag"]),
+                     max_occ=int(g["mid_occ"]), index=[g["img_B"], g["img_H"], g["img_V"], g["img_P"]]) as drv:
+        n_pkts = 0
+        for k in range(0, n_reads, 8):
+            drv.submit(fpga.build_task_packet(reads[k:k + 8], par.max_dist_x, par.max_dist_y, pkt_type=fpga.PKT_MINIMIZERS), tid=k // 8)
+            n_pkts += 1
+        results = drv.wait_results(n_pkts)
+        st = drv.stats()
+    assert st["err_reads"] == 0 and st["reads"] == n_reads and st["anchors"] == len(g["anchors"])
+    seen = {}
+    for raw in results:
+        for read_id, err, seeds, mini_pos, rep_len in fpga.parse_result_packet_full(raw):
+            assert err == 0
+            seen[read_id] = (seeds, mini_pos, rep_len)
+    assert sorted(seen) == list(range(n_reads))
+    for r in range(n_reads):
+        a = np.ascontiguousarray(g["anchors"][g["a_off"][r]:g["a_off"][r + 1]])
+        f, p, v, _ = ol.oracle_fpv(par, a)
+        exp = ol.oracle_compact(par, a, f, p, v)
+        assert seen[r][0].tobytes() == exp.tobytes(), (os.path.basename(path), r, "new_seed[]")
+        assert np.array_equal(seen[r][1], g["mini_pos"][g["mp_off"][r]:g["mp_off"][r + 1]]), (r, "mini_pos")
+        assert seen[r][2] == int(g["rep_len"][r]), (r, "rep_len")
