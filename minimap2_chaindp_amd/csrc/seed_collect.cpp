@@ -92,6 +92,22 @@ const uint64_t *IndexImage::get(uint64_t minier, int *n) const
 	}
 }
 
+// Lookups are four dependent cache misses (B entry, hash group, value, positions) into an image far larger than
+// the caches; the caller walks a read's minimizers in order, so the first two levels are prefetched a few
+// minimizers ahead.
+void IndexImage::prefetch(uint64_t minier, int level) const
+{
+	if (B_.empty() || b_bits_ < 0) return;
+	const uint8_t *be = B_.data() + (minier & ((1ull << b_bits_) - 1)) * 16;
+	if (level == 0) { __builtin_prefetch(be); return; }
+	const uint64_t w0 = load_u64(be), w1 = load_u64(be + 8);
+	const uint32_t n_buckets = (uint32_t)(w0 >> 24);
+	if (n_buckets == 0) return;
+	const uint64_t slot = (w1 >> 28) + ((uint32_t)(minier >> b_bits_) & (n_buckets - 1));
+	if ((slot >> 3) * 64 + 64 <= H_.size()) __builtin_prefetch(H_.data() + (slot >> 3) * 64);
+	if ((slot + 1) * 8 <= V_.size()) __builtin_prefetch(V_.data() + slot * 8);
+}
+
 // ---- radix_sort_128x, ksort.h:101-151 with rskey = x, sizeof_key = 8, RS_MIN_SIZE 64, RS_MAX_BITS 8
 
 static void insertion_sort_x(U128 *beg, U128 *end)                   // ksort.h:107-117
@@ -183,6 +199,8 @@ void collect_seed_hits(const IndexImage &idx, int flag, int max_occ, const U128 
 		const U128 &p = mv[i];
 		const uint32_t q_pos = (uint32_t)p.y, q_span = (uint32_t)(p.x & 0xff);
 		int t;
+		if (i + 16 < mv_n) idx.prefetch(mv[i + 16].x >> 8, 0);
+		if (i + 8 < mv_n) idx.prefetch(mv[i + 8].x >> 8, 1);
 		const uint64_t *cr = idx.get(p.x >> 8, &t);
 		if (t >= max_occ) {                                            // too frequent: only its span counts, as repetitive
 			const int en = (int)(q_pos >> 1) + 1, st = en - (int)q_span;

@@ -29,6 +29,7 @@ public:
 	void clear();
 	// mm_idx_get (index.c:221-238) over the image: positions of minimizer `minier`, *n of them (0 if absent)
 	const uint64_t *get(uint64_t minier, int *n) const;
+	void prefetch(uint64_t minier, int level) const;           // level 0: bucket entry; 1: first hash group and value
 private:
 	void seal();
 	std::vector<uint8_t> B_, H_, V_, P_;
