@@ -121,6 +121,25 @@ int chaindp_upload_gather_ex(chaindp_ctx_t *ctx, int64_t n_reads, const int64_t 
                              const chaindp_anchor_t *const *read_anchors, const int32_t *n_segs_per_read, int pinned);
 int chaindp_scatter_seeds(chaindp_ctx_t *ctx, int64_t n_reads, chaindp_seed_t *const *dst);
 
+/* ---- seed collection on the GPU ----------------------------------------
+ * What the reference's device does with a read's minimizers before chaining: collect_seed_hits (map.c:187-236,
+ * called from fpga_work, map.c:523) -- lookup in the index image the host streams through fpga_load_index
+ * (index.c:603-720: blobs B, H, V, P, types 4..7), skip_seed, the anchors in generation order, rep_len, mini_pos,
+ * and radix_sort_128x exactly as the reference runs it (the order of equal x is input to the DP).
+ * chaindp_index_create copies the four blobs to `device`.  chaindp_collect_seeds takes the minimizers of a batch
+ * (CSR: mini_off[n_reads+1], mini as collect_minimizers leaves them, map.c:352; bid and qlen per read as in
+ * collect_task_t) and leaves the sorted anchors resident in ctx exactly as chaindp_upload would (chaindp_run /
+ * chaindp_run_full follow); it returns the per-read anchor offsets, rep_len and mini_pos offsets.  Synchronous. */
+typedef struct chaindp_index chaindp_index_t;
+chaindp_index_t *chaindp_index_create(int device, const void *B, size_t nB, const void *H, size_t nH,
+                                      const void *V, size_t nV, const void *P, size_t nP);
+void chaindp_index_destroy(chaindp_index_t *idx);
+int chaindp_collect_seeds(chaindp_ctx_t *ctx, const chaindp_index_t *idx, int flag, int max_occ, int64_t n_reads,
+                          const int64_t *mini_off, const chaindp_anchor_t *mini, const uint32_t *bid, const int32_t *qlen,
+                          const int32_t *n_segs_per_read, int64_t *off, int32_t *rep_len, int64_t *mini_pos_off);
+int chaindp_download_mini_pos(chaindp_ctx_t *ctx, uint64_t *mini_pos);      /* mini_pos_off[n_reads] entries */
+int chaindp_download_anchors(chaindp_ctx_t *ctx, chaindp_anchor_t *a);      /* the resident batch's anchors */
+
 /* Pinned host memory (hipHostMalloc) for callers that want DMA-able staging buffers. */
 void *chaindp_host_alloc(size_t bytes);
 void chaindp_host_free(void *p);

@@ -24,6 +24,7 @@ ABI_SYMBOLS = (
     "chaindp_upload_gather", "chaindp_compact_offsets", "chaindp_download_seeds", "chaindp_host_alloc",
     "chaindp_host_free", "chaindp_run_device", "chaindp_set_profiling", "chaindp_get_kernel_ms",
     "chaindp_get_stats", "chaindp_set_ring", "chaindp_run_full", "chaindp_set_variant", "chaindp_upload_gather_ex", "chaindp_scatter_seeds", "chaindp_backtrack",
+    "chaindp_index_create", "chaindp_index_destroy", "chaindp_collect_seeds", "chaindp_download_mini_pos", "chaindp_download_anchors",
 )
 
 
@@ -69,6 +70,13 @@ def lib():
         L.chaindp_set_ring.argtypes = [vp, i32]
         L.chaindp_set_variant.argtypes = [vp, i32]
         L.chaindp_backtrack.argtypes = [vp, P, i32, vp, vp, vp, vp]
+        L.chaindp_index_create.restype = vp
+        L.chaindp_index_create.argtypes = [i32, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t]
+        L.chaindp_index_destroy.restype = None
+        L.chaindp_index_destroy.argtypes = [vp]
+        L.chaindp_collect_seeds.argtypes = [vp, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.chaindp_download_mini_pos.argtypes = [vp, vp]
+        L.chaindp_download_anchors.argtypes = [vp, vp]
         _lib = L
     return _lib
 
@@ -94,12 +102,16 @@ class Device:
         self.device = device
         self.max_anchors, self.max_reads = max_anchors, max_reads
         self._n_reads = self._total = 0
+        self._indexes = []
         if ring is not None:
             self._check(self._lib.chaindp_set_ring(self._ctx, ring))
 
     # -- lifecycle
     def close(self):
         if self._ctx:
+            for h in self._indexes:
+                self._lib.chaindp_index_destroy(h)
+            self._indexes = []
             self._lib.chaindp_destroy(self._ctx)
             self._ctx = None
 
@@ -180,6 +192,34 @@ class Device:
         b = np.zeros((cap, 2), np.uint64)
         self._check(self._lib.chaindp_backtrack(self._ctx, C.byref(par), min_cnt, _ptr(coff), _ptr(u), _ptr(boff), _ptr(b)))
         return coff, u[:int(coff[-1])], boff, b[:int(boff[-1])]
+
+    # -- seed collection on the GPU (collect_seed_hits, map.c:187-236, over the FPGA index image)
+    def load_index(self, img):
+        """img: the four blobs B, H, V, P of the reference's index image (index.c:603-720) -> a handle for collect_seeds."""
+        blobs = [np.ascontiguousarray(b, np.uint8) for b in img]
+        h = self._lib.chaindp_index_create(self.device, *sum(([_ptr(b) if b.size else None, int(b.size)] for b in blobs), []))
+        if not h:
+            raise ChainDPError((self._lib.chaindp_last_error(None) or b"").decode())
+        self._indexes.append(h)
+        return h
+
+    def collect_seeds(self, index, flag, max_occ, mini_off, mini, bid, qlen, n_segs=None):
+        """Minimizers of a batch -> sorted anchors resident on the device (as after upload()).  Returns (off int64[n_reads+1],
+        anchors uint64[n,2], rep_len int32[n_reads], mini_pos_off, mini_pos uint64[...])."""
+        mini_off = np.ascontiguousarray(mini_off, np.int64)
+        n_reads = len(mini_off) - 1
+        mini = np.ascontiguousarray(mini, np.uint64).reshape(-1, 2)
+        bid = np.ascontiguousarray(bid, np.uint32); qlen = np.ascontiguousarray(qlen, np.int32)
+        off = np.zeros(n_reads + 1, np.int64); mpo = np.zeros(n_reads + 1, np.int64); rep = np.zeros(max(n_reads, 1), np.int32)
+        ns = None if n_segs is None else np.ascontiguousarray(n_segs, np.int32)
+        self._check(self._lib.chaindp_collect_seeds(self._ctx, index, int(flag), int(max_occ), n_reads, _ptr(mini_off), _ptr(mini), _ptr(bid),
+                                                    _ptr(qlen), _ptr(ns), _ptr(off), _ptr(rep), _ptr(mpo)))
+        self._n_reads, self._total = n_reads, int(off[-1])
+        a = np.zeros((max(self._total, 1), 2), np.uint64)
+        self._check(self._lib.chaindp_download_anchors(self._ctx, _ptr(a)))
+        mp = np.zeros(max(int(mpo[-1]), 1), np.uint64)
+        self._check(self._lib.chaindp_download_mini_pos(self._ctx, _ptr(mp)))
+        return off, a[:self._total], rep[:n_reads], mpo, mp[:int(mpo[-1])]
 
     # -- device-pointer path (torch tensors or any other HBM allocation)
     def run_device(self, par, n_reads, total, d_off, d_a, d_n_segs, d_f, d_p, d_v, stream=0):

@@ -49,6 +49,14 @@ struct chaindp_ctx {
 	int32_t *d_first_child = nullptr, *d_id = nullptr;
 	int64_t *d_seeds_off = nullptr;
 	void *d_seeds = nullptr;
+	// seed collection (allocated on first use, grown with the batch)
+	chaindp::SeedScratch seed = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	void *d_mini = nullptr;
+	int64_t *d_mini_off = nullptr, *d_mp_off = nullptr;
+	uint32_t *d_bid = nullptr;
+	int32_t *d_qlen = nullptr, *d_rep_len = nullptr;
+	unsigned long long *d_mini_pos = nullptr;
+	int64_t seed_cap_mini = 0, n_mini_pos = 0;
 	// profiling
 	bool prof = false;
 	std::vector<EventSet> pending;
@@ -109,6 +117,9 @@ extern "C" void chaindp_destroy(chaindp_ctx_t *ctx)
 	                ctx->d_counters, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->pre.units_tmp, ctx->pre.hist, ctx->pre.block_reads, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
 	for (void *b : bufs) if (b) (void)hipFree(b);
 	for (void *b : ctx->bot_allocs) if (b) (void)hipFree(b);
+	void *sbufs[] = {ctx->seed.kept, ctx->seed.used, ctx->seed.src, ctx->seed.mstate, ctx->seed.tile_tmp, ctx->seed.totals, ctx->seed.stacks,
+	                 ctx->d_mini, ctx->d_mini_off, ctx->d_mp_off, ctx->d_bid, ctx->d_qlen, ctx->d_rep_len, ctx->d_mini_pos};
+	for (void *b : sbufs) if (b) (void)hipFree(b);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -592,5 +603,143 @@ extern "C" int chaindp_get_stats(chaindp_ctx_t *ctx, int64_t st[4])
 	HIP_TRY(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
 	ctx->stats[0] = (int64_t)(c & 0xffffffffull); ctx->stats[1] = (int64_t)(c >> 32);
 	for (int k = 0; k < 4; ++k) st[k] = ctx->stats[k];
+	return CHAINDP_OK;
+}
+
+// ---- seed collection on the GPU (chaindp_seed.hip)
+
+struct chaindp_index {
+	int device = -1;
+	uint8_t *blob[4] = {nullptr, nullptr, nullptr, nullptr};
+	size_t bytes[4] = {0, 0, 0, 0};
+	int b_bits = 0;
+};
+
+extern "C" chaindp_index_t *chaindp_index_create(int device, const void *B, size_t nB, const void *H, size_t nH,
+                                                 const void *V, size_t nV, const void *P, size_t nP)
+{
+	g_create_error.clear();
+	if (!B || nB < 16 || !H || !V) { g_create_error = "chaindp_index_create: the image needs its B, H and V blobs"; return nullptr; }
+	if (hipSetDevice(device) != hipSuccess) { g_create_error = "chaindp_index_create: no such HIP device (there is no CPU fallback)"; return nullptr; }
+	chaindp_index *ix = new chaindp_index();
+	ix->device = device;
+	const void *src[4] = {B, H, V, P};
+	const size_t nb[4] = {nB, nH, nV, nP};
+	for (int k = 0; k < 4; ++k) {
+		ix->bytes[k] = nb[k];
+		const size_t alloc = (nb[k] + 63) & ~(size_t)63;                 // the kernels read whole 64-byte groups
+		if (hipMalloc((void**)&ix->blob[k], alloc ? alloc : 64) != hipSuccess ||
+		    hipMemset(ix->blob[k], 0, alloc ? alloc : 64) != hipSuccess ||
+		    (nb[k] && hipMemcpy(ix->blob[k], src[k], nb[k], hipMemcpyHostToDevice) != hipSuccess)) {
+			g_create_error = "chaindp_index_create: out of device memory";
+			chaindp_index_destroy(ix);
+			return nullptr;
+		}
+	}
+	size_t entries = nB / 16;
+	while ((size_t)2 << ix->b_bits <= entries) ++ix->b_bits;          // one 16-byte entry per bucket, 2^b buckets
+	return ix;
+}
+
+extern "C" void chaindp_index_destroy(chaindp_index_t *ix)
+{
+	if (!ix) return;
+	if (ix->device >= 0) (void)hipSetDevice(ix->device);
+	for (int k = 0; k < 4; ++k) if (ix->blob[k]) (void)hipFree(ix->blob[k]);
+	delete ix;
+}
+
+static int seed_reserve(chaindp_ctx *ctx, int64_t n_mini)
+{
+	if (!ctx->d_mini_off) {
+		const size_t nr = (size_t)ctx->cap_reads;
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_mini_off, (nr + 1) * 8));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_mp_off, (nr + 1) * 8));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bid, (nr + 1) * 4));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qlen, (nr + 1) * 4));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_rep_len, (nr + 1) * 4));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->seed.totals, 16));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->seed.stacks, ((size_t)ctx->cap_anchors / 64 + 2 * nr + 4) * 12));
+	}
+	if (n_mini > ctx->seed_cap_mini) {
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		void **grow[] = {(void**)&ctx->seed.kept, (void**)&ctx->seed.used, (void**)&ctx->seed.src, (void**)&ctx->seed.mstate,
+		                 (void**)&ctx->seed.tile_tmp, (void**)&ctx->d_mini, (void**)&ctx->d_mini_pos};
+		for (void **g : grow) if (*g) { HIP_TRY(ctx, hipFree(*g)); *g = nullptr; }
+		ctx->seed_cap_mini = 0;
+		const size_t n = (size_t)n_mini + (size_t)n_mini / 4 + 1024;
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->seed.kept, n * 8));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->seed.used, n * 8));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->seed.src, n * 8));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->seed.mstate, n * 8));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->seed.tile_tmp, (n / 1024 + 2) * 8));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_mini, n * 16));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_mini_pos, n * 8));
+		ctx->seed_cap_mini = (int64_t)n;
+	}
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_collect_seeds(chaindp_ctx_t *ctx, const chaindp_index_t *ix, int flag, int max_occ, int64_t n_reads,
+                                     const int64_t *mini_off, const chaindp_anchor_t *mini, const uint32_t *bid, const int32_t *qlen,
+                                     const int32_t *n_segs_per_read, int64_t *off, int32_t *rep_len, int64_t *mini_pos_off)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	if (!ix || ix->device != ctx->device) { ctx->err = "index image missing or on another device"; return CHAINDP_ERR_ARG; }
+	if (n_reads < 0 || !mini_off || (n_reads > 0 && (mini_off[0] != 0 || !bid || !qlen))) { ctx->err = "bad minimizer offsets"; return CHAINDP_ERR_ARG; }
+	const int64_t n_mini = n_reads > 0 ? mini_off[n_reads] : 0;
+	if (n_mini < 0 || (n_mini > 0 && !mini)) { ctx->err = "bad minimizers"; return CHAINDP_ERR_ARG; }
+	if (n_reads > ctx->cap_reads) { ctx->err = "batch exceeds the capacity the context was created with"; return CHAINDP_ERR_CAPACITY; }
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc = seed_reserve(ctx, n_mini);
+	if (rc) return rc;
+	hipStream_t st = ctx->stream;
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mini_off, mini_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+	if (n_mini) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mini, mini, (size_t)n_mini * 16, hipMemcpyHostToDevice, st));
+	if (n_reads) {
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bid, bid, (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_qlen, qlen, (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
+	}
+	ctx->has_n_segs = n_segs_per_read != nullptr;
+	if (n_segs_per_read && n_reads) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_n_segs, n_segs_per_read, (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
+	chaindp::SeedIndex dix;
+	dix.B = ix->blob[0]; dix.H = ix->blob[1]; dix.V = ix->blob[2]; dix.P = ix->blob[3];
+	dix.nB = ix->bytes[0]; dix.nH = ix->bytes[1]; dix.nV = ix->bytes[2]; dix.nP = ix->bytes[3];
+	dix.b_bits = ix->b_bits;
+	HIP_TRY(ctx, chaindp::launch_seed_collect(st, dix, flag, max_occ, n_reads, n_mini, ctx->d_mini_off, ctx->d_mini, ctx->d_bid, ctx->d_qlen,
+	                                          ctx->seed, ctx->d_a, ctx->d_off, ctx->d_mp_off, ctx->d_rep_len, ctx->d_mini_pos));
+	unsigned long long totals[2] = {0, 0};
+	HIP_TRY(ctx, hipMemcpyAsync(totals, ctx->seed.totals, 16, hipMemcpyDeviceToHost, st));
+	HIP_TRY(ctx, hipStreamSynchronize(st));
+	if ((int64_t)totals[0] > ctx->cap_anchors) {
+		ctx->n_reads = 0; ctx->total = 0; ctx->ran = false;
+		ctx->err = "the batch's seeds exceed the anchor capacity the context was created with";
+		return CHAINDP_ERR_CAPACITY;
+	}
+	HIP_TRY(ctx, chaindp::launch_seed_expand_sort(st, dix, flag, n_reads, n_mini, ctx->d_mini_off, ctx->d_mini, ctx->d_bid, ctx->d_qlen, ctx->seed,
+	                                              ctx->d_a, ctx->d_off, ctx->d_mini_pos));
+	if (off) HIP_TRY(ctx, hipMemcpyAsync(off, ctx->d_off, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, st));
+	if (mini_pos_off) HIP_TRY(ctx, hipMemcpyAsync(mini_pos_off, ctx->d_mp_off, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, st));
+	if (rep_len && n_reads) HIP_TRY(ctx, hipMemcpyAsync(rep_len, ctx->d_rep_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(ctx, hipStreamSynchronize(st));
+	ctx->n_reads = n_reads; ctx->total = (int64_t)totals[0]; ctx->n_mini_pos = (int64_t)totals[1]; ctx->ran = false;
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_download_mini_pos(chaindp_ctx_t *ctx, uint64_t *mini_pos)
+{
+	if (!ctx || (ctx->n_mini_pos > 0 && !mini_pos)) return CHAINDP_ERR_ARG;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (ctx->n_mini_pos) HIP_TRY(ctx, hipMemcpyAsync(mini_pos, ctx->d_mini_pos, (size_t)ctx->n_mini_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_download_anchors(chaindp_ctx_t *ctx, chaindp_anchor_t *a)
+{
+	if (!ctx || (ctx->total > 0 && !a)) return CHAINDP_ERR_ARG;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (ctx->total) HIP_TRY(ctx, hipMemcpyAsync(a, ctx->d_a, (size_t)ctx->total * 16, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return CHAINDP_OK;
 }

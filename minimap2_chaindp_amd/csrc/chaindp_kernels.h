@@ -82,6 +82,28 @@ struct BottomScratch {
 hipError_t launch_backtrack(hipStream_t st, int min_cnt, int min_sc, int64_t n_reads, int64_t m_cap, const int64_t *d_soff, const void *d_seeds,
                             const unsigned long long *d_n_seeds, BottomScratch sc, int64_t n_seeds_host);
 
+// seed collection on the GPU (reference map.c:112-236 over the FPGA index image, index.c:603-720): chaindp_seed.hip
+struct SeedIndex {                   // the four blobs of the image in HBM (layout: seed_collect.h)
+	const uint8_t *B, *H, *V, *P;
+	uint64_t nB, nH, nV, nP;         // bytes
+	int b_bits;                      // log2 of the bucket count
+};
+struct SeedScratch {                 // n = minimizers of the batch
+	unsigned long long *kept, *used; // n each: anchors / used minimizers per minimizer, scanned in place
+	unsigned long long *src, *mstate;// n each: where its hits are; hits | used << 32 | tandem << 33
+	unsigned long long *tile_tmp;    // scan scratch, n / 1024 + 2
+	unsigned long long *totals;      // 2: anchors, used minimizers
+	void *stacks;                    // (max_anchors / 64 + 2 R + 4) x 12 B for the per-read sort
+};
+// phase 1: probe, scans, per-read offsets and rep_len; the host then reads off[n_reads] (capacity check) and runs
+// phase 2: expand (anchors in generation order, mini_pos) and the per-read radix_sort_128x
+hipError_t launch_seed_collect(hipStream_t st, const SeedIndex &ix, int flag, int max_occ, int64_t n_reads, int64_t n_mini,
+                               const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, const int32_t *d_qlen, SeedScratch sc,
+                               void *d_a, int64_t *d_off, int64_t *d_mp_off, int32_t *d_rep_len, unsigned long long *d_mini_pos);
+hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag, int64_t n_reads, int64_t n_mini,
+                                   const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, const int32_t *d_qlen, SeedScratch sc,
+                                   void *d_a, const int64_t *d_off, unsigned long long *d_mini_pos);
+
 // zero-copy movement between device-visible (pinned) host buffers and HBM: chaindp_io.hip
 hipError_t launch_gather_reads(hipStream_t st, int64_t n_reads, const int64_t *d_off, const void *const *d_src, void *d_a);
 hipError_t launch_scatter_seeds(hipStream_t st, int64_t n_reads, const int64_t *d_seeds_off, void *const *d_dst, const void *d_seeds);

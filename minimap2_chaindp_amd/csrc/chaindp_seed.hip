@@ -1,0 +1,240 @@
+// chaindp_seed.hip -- seed collection on the GPU: what the reference's device did with a read's
+// minimizers before chaining (collect_seed_hits, map.c:187-236, called from fpga_work, map.c:523), over the index
+// image the host streams through fpga_load_index (index.c:603-720).
+//
+//   k_seed_probe   thread per minimizer: mm_idx_get over the image (khash probe, khash.h:218-231), the
+//                  "too frequent" test and tandem flag of collect_matches (map.c:112-146), and the number of its
+//                  hits that survive skip_seed (map.c:148-185)
+//   (two exclusive scans: anchors before each minimizer, used minimizers before each minimizer)
+//   k_seed_expand  thread per minimizer: writes its surviving hits as anchors (map.c:197-231), in the reference's
+//                  generation order, and its mini_pos entry
+//   k_seed_reads   thread per read: anchor / mini_pos offsets of the read and rep_len (the interval merge of
+//                  map.c:127-133 is sequential in the minimizers, 2-3 k steps)
+//   k_seed_sort    thread per read: radix_sort_128x exactly as the reference runs it (chaindp_rsort.h); the order of
+//                  equal x is input to the chaining DP
+// Image layout: see csrc/seed_collect.h (the host-side statement of the same lookup, pinned on the CPU tier).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "chaindp_kernels.h"
+#include "chaindp_rsort.h"
+
+namespace chaindp {
+
+#define SEED_P_STRAND (1ull << 21)              // mmpriv.h:20
+#define SEED_TANDEM_BIT (1ull << 42)            // mmpriv.h:18
+#define SEED_SELF_BIT (1ull << 43)              // mmpriv.h:19
+#define SEED_SEG_SHIFT 48                       // mmpriv.h:22
+#define SEED_F_NO_DIAG 0x001
+#define SEED_F_NO_DUAL 0x002
+#define SEED_F_FOR_ONLY 0x100000
+#define SEED_F_REV_ONLY 0x200000
+
+__device__ __forceinline__ uint64_t ld_u64(const uint8_t *p) { return *(const uint64_t*)p; }      // all blobs are 8-byte aligned at these offsets
+
+// 6-byte key at an even address (group base is 64-aligned, keys start at +4, 6 bytes each)
+__device__ __forceinline__ uint64_t ld_u48(const uint8_t *p)
+{
+	const uint16_t *q = (const uint16_t*)p;
+	return (uint64_t)q[0] | (uint64_t)q[1] << 16 | (uint64_t)q[2] << 32;
+}
+
+// mm_idx_get over the image (index.c:221-238): *n hits; returns their location as an index into V (single hit,
+// bit 63 set) or into P
+__device__ __forceinline__ uint64_t seed_lookup(const SeedIndex &ix, uint64_t minier, int *n)
+{
+	*n = 0;
+	const uint64_t mask = (1ull << ix.b_bits) - 1;
+	const uint8_t *be = ix.B + (minier & mask) * 16;
+	const uint64_t w0 = ld_u64(be), w1 = ld_u64(be + 8);
+	const uint32_t n_buckets = (uint32_t)(w0 >> 24);
+	if (n_buckets == 0) return 0;
+	const uint64_t h_off = w1 >> 28, p_off = (w1 & ((1ull << 28) - 1)) << 8 | w0 >> 56;
+	const uint64_t key = minier >> ix.b_bits << 1;
+	const uint32_t m = n_buckets - 1;
+	uint32_t i = (uint32_t)(key >> 1) & m, step = 0;
+	const uint32_t last = i;
+	for (;;) {
+		const uint64_t slot = h_off + i;
+		if ((slot >> 3) * 64 + 64 > ix.nH) return 0;
+		const uint8_t *grp = ix.H + (slot >> 3) * 64;
+		const uint32_t fl = (*(const uint32_t*)grp >> ((i & 0xfu) << 1)) & 3u;
+		if (fl & 2u) return 0;                                            // empty: absent
+		const uint64_t k48 = ld_u48(grp + 4 + (slot & 7) * 6);
+		if (!(fl & 1u) && (k48 >> 1) == ((key & 0xffffffffffffull) >> 1)) {
+			if ((slot + 1) * 8 > ix.nV) return 0;
+			if (k48 & 1) { *n = 1; return 1ull << 63 | slot; }
+			const uint64_t v = ld_u64(ix.V + slot * 8);
+			const uint64_t first = p_off + (v >> 32);
+			const uint32_t cnt = (uint32_t)v;
+			if ((first + cnt) * 8 > ix.nP) return 0;
+			*n = (int)cnt;
+			return first;
+		}
+		i = (i + (++step)) & m;
+		if (i == last) return 0;
+	}
+}
+
+__device__ __forceinline__ const uint64_t *seed_hits(const SeedIndex &ix, uint64_t src)
+{
+	return (src >> 63) ? (const uint64_t*)(ix.V + (src & ~(1ull << 63)) * 8) : (const uint64_t*)(ix.P + src * 8);
+}
+
+// skip_seed, map.c:148-185 (the block at :152 opens on bit 0 of flag only, as written)
+__device__ __forceinline__ bool seed_skip(int flag, uint64_t r, uint32_t q_pos, uint32_t bid, bool *is_self)
+{
+	*is_self = false;
+	if (1 & flag & (SEED_F_NO_DIAG | SEED_F_NO_DUAL)) {
+		const uint32_t rank_id = (uint32_t)r & 0x1FFFFFu, val = bid & 0x7fffffffu;
+		const int cmp = val > rank_id ? 1 : val < rank_id ? -1 : (bid >> 31) ? 0 : -1;
+		if ((flag & SEED_F_NO_DIAG) && cmp == 0) {
+			if (((r >> 22) & 0x1fffff) == (q_pos >> 1)) return true;
+			if (((r & SEED_P_STRAND) >> 21) == (q_pos & 1)) *is_self = true;
+		}
+		if ((flag & SEED_F_NO_DUAL) && cmp > 0) return true;
+	}
+	if (flag & (SEED_F_FOR_ONLY | SEED_F_REV_ONLY)) {
+		if (((r & SEED_P_STRAND) >> 21) == (q_pos & 1)) { if (flag & SEED_F_REV_ONLY) return true; }
+		else { if (flag & SEED_F_FOR_ONLY) return true; }
+	}
+	return false;
+}
+
+// largest r in [0, n_reads) with mini_off[r] <= i
+__device__ __forceinline__ int64_t seed_read_of(const int64_t *__restrict__ mini_off, int64_t n_reads, int64_t i)
+{
+	int64_t lo = 0, hi = n_reads - 1;
+	while (lo < hi) {
+		const int64_t mid = (lo + hi + 1) >> 1;
+		if (mini_off[mid] <= i) lo = mid; else hi = mid - 1;
+	}
+	return lo;
+}
+
+// per minimizer: mstate = hits (low 32 bits) | used << 32 | tandem << 33; src = where its hits are
+__global__ __launch_bounds__(256) void k_seed_probe(SeedIndex ix, int flag, int max_occ, int64_t n_reads, int64_t n_mini,
+                                                    const int64_t *__restrict__ mini_off, const ulonglong2 *__restrict__ mini,
+                                                    const uint32_t *__restrict__ bid, unsigned long long *__restrict__ kept,
+                                                    unsigned long long *__restrict__ used, unsigned long long *__restrict__ src,
+                                                    unsigned long long *__restrict__ mstate)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_mini) return;
+	const ulonglong2 p = mini[i];
+	const int64_t r = seed_read_of(mini_off, n_reads, i);
+	int t;
+	const uint64_t where = seed_lookup(ix, p.x >> 8, &t);
+	unsigned long long k = 0, st = 0;
+	if (t < max_occ) {                                                    // map.c:125: a used minimizer (also when it has no hit)
+		const bool tandem = (i > mini_off[r] && p.x >> 8 == mini[i - 1].x >> 8) || (i + 1 < mini_off[r + 1] && p.x >> 8 == mini[i + 1].x >> 8);
+		const uint64_t *cr = t ? seed_hits(ix, where) : nullptr;
+		const uint32_t q_pos = (uint32_t)p.y, b = bid[r];
+		for (int h = 0; h < t; ++h) { bool self; if (!seed_skip(flag, cr[h], q_pos, b, &self)) ++k; }
+		st = (unsigned long long)(uint32_t)t | 1ull << 32 | (unsigned long long)tandem << 33;
+	}
+	kept[i] = k; used[i] = st >> 32 & 1; src[i] = where; mstate[i] = st;
+}
+
+__global__ __launch_bounds__(256) void k_seed_expand(SeedIndex ix, int flag, int64_t n_reads, int64_t n_mini,
+                                                     const int64_t *__restrict__ mini_off, const ulonglong2 *__restrict__ mini,
+                                                     const uint32_t *__restrict__ bid, const int32_t *__restrict__ qlen,
+                                                     const unsigned long long *__restrict__ kept_pos, const unsigned long long *__restrict__ used_pos,
+                                                     const unsigned long long *__restrict__ src, const unsigned long long *__restrict__ mstate,
+                                                     ulonglong2 *__restrict__ a, unsigned long long *__restrict__ mini_pos)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_mini) return;
+	const unsigned long long st = mstate[i];
+	if (!(st >> 32 & 1)) return;
+	const ulonglong2 p = mini[i];
+	const uint32_t q_pos = (uint32_t)p.y, q_span = (uint32_t)(p.x & 0xff);
+	mini_pos[used_pos[i]] = (unsigned long long)q_span << 32 | q_pos >> 1;               // map.c:141
+	const int t = (int)(uint32_t)st;
+	if (t == 0) return;
+	const int64_t r = seed_read_of(mini_off, n_reads, i);
+	const uint32_t b = bid[r], ql = (uint32_t)qlen[r];
+	const uint64_t seg = (uint64_t)((uint32_t)(p.y >> 32) & 0x7fffffffu) << SEED_SEG_SHIFT;
+	const uint64_t extra = seg | ((st >> 33 & 1) ? SEED_TANDEM_BIT : 0);
+	const uint64_t *cr = seed_hits(ix, src[i]);
+	unsigned long long o = kept_pos[i];
+	for (int h = 0; h < t; ++h) {
+		const uint64_t rr = cr[h];
+		bool self;
+		if (seed_skip(flag, rr, q_pos, b, &self)) continue;
+		const uint64_t rpos = (rr >> 22) & 0x1fffff;
+		ulonglong2 s;
+		if (((rr & SEED_P_STRAND) >> 21) == (q_pos & 1)) {                               // forward strand, map.c:216-218
+			s.x = ((rr & 0xfffff80000000000ull) >> 11) | rpos;
+			s.y = (uint64_t)q_span << 32 | q_pos >> 1;
+		} else {                                                                         // reverse strand, map.c:220-222 (32-bit unsigned arithmetic)
+			s.x = 1ull << 63 | ((rr & 0xfffff80000000000ull) >> 11) | rpos;
+			s.y = (uint64_t)q_span << 32 | (uint32_t)(ql - ((q_pos >> 1) + 1 - q_span) - 1);
+		}
+		s.y |= extra;
+		if (self) s.y |= SEED_SELF_BIT;
+		a[o++] = s;
+	}
+}
+
+__global__ __launch_bounds__(64) void k_seed_reads(int64_t n_reads, int64_t n_mini, const int64_t *__restrict__ mini_off,
+                                                   const ulonglong2 *__restrict__ mini, const unsigned long long *__restrict__ kept_pos,
+                                                   const unsigned long long *__restrict__ used_pos, const unsigned long long *__restrict__ mstate,
+                                                   const unsigned long long *__restrict__ totals, int64_t *__restrict__ off,
+                                                   int64_t *__restrict__ mp_off, int32_t *__restrict__ rep_len)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r > n_reads) return;
+	if (r == n_reads) { off[r] = (int64_t)totals[0]; mp_off[r] = (int64_t)totals[1]; return; }
+	const int64_t b = mini_off[r], e = mini_off[r + 1];
+	off[r] = b < n_mini ? (int64_t)kept_pos[b] : (int64_t)totals[0];
+	mp_off[r] = b < n_mini ? (int64_t)used_pos[b] : (int64_t)totals[1];
+	int rep_st = 0, rep_en = 0, rl = 0;                                                  // map.c:116,127-133,143
+	for (int64_t i = b; i < e; ++i) {
+		if (mstate[i] >> 32 & 1) continue;
+		const ulonglong2 p = mini[i];
+		const int en = (int)((uint32_t)p.y >> 1) + 1, st = en - (int)(p.x & 0xff);
+		if (st > rep_en) { rl += rep_en - rep_st; rep_st = st; rep_en = en; }
+		else rep_en = en;
+	}
+	rep_len[r] = rl + rep_en - rep_st;
+}
+
+__global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, const int64_t *__restrict__ off, ulonglong2 *__restrict__ a, BtRange *__restrict__ stacks)
+{
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	const int64_t b = off[r];
+	const int64_t n = off[r + 1] - b;
+	if (n > 1) bt_radix_128x(a + b, (int32_t)n, stacks + b / 64 + 2 * r);               // map.c:233
+}
+
+hipError_t launch_seed_collect(hipStream_t st, const SeedIndex &ix, int flag, int max_occ, int64_t n_reads, int64_t n_mini,
+                               const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, const int32_t *d_qlen, SeedScratch sc,
+                               void *d_a, int64_t *d_off, int64_t *d_mp_off, int32_t *d_rep_len, unsigned long long *d_mini_pos)
+{
+	hipError_t e;
+	if (n_mini > 0) {
+		hipLaunchKernelGGL(k_seed_probe, dim3((unsigned)((n_mini + 255) / 256)), dim3(256), 0, st, ix, flag, max_occ, n_reads, n_mini, d_mini_off,
+		                   (const ulonglong2*)d_mini, d_bid, sc.kept, sc.used, sc.src, sc.mstate);
+	}
+	if ((e = launch_scan_u64(st, n_mini, sc.kept, sc.tile_tmp, sc.totals)) != hipSuccess) return e;
+	if ((e = launch_scan_u64(st, n_mini, sc.used, sc.tile_tmp, sc.totals + 1)) != hipSuccess) return e;
+	hipLaunchKernelGGL(k_seed_reads, dim3((unsigned)((n_reads + 1 + 63) / 64)), dim3(64), 0, st, n_reads, n_mini, d_mini_off, (const ulonglong2*)d_mini,
+	                   sc.kept, sc.used, sc.mstate, sc.totals, d_off, d_mp_off, d_rep_len);
+	return hipGetLastError();
+}
+
+hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag, int64_t n_reads, int64_t n_mini,
+                                   const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, const int32_t *d_qlen, SeedScratch sc,
+                                   void *d_a, const int64_t *d_off, unsigned long long *d_mini_pos)
+{
+	if (n_mini > 0) {
+		hipLaunchKernelGGL(k_seed_expand, dim3((unsigned)((n_mini + 255) / 256)), dim3(256), 0, st, ix, flag, n_reads, n_mini, d_mini_off,
+		                   (const ulonglong2*)d_mini, d_bid, d_qlen, sc.kept, sc.used, sc.src, sc.mstate, (ulonglong2*)d_a, d_mini_pos);
+	}
+	if (n_reads > 0)
+		hipLaunchKernelGGL(k_seed_sort, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, st, n_reads, d_off, (ulonglong2*)d_a, (BtRange*)sc.stacks);
+	return hipGetLastError();
+}
+
+} // namespace chaindp
