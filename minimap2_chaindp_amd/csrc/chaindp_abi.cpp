@@ -57,6 +57,7 @@ struct chaindp_ctx {
 	int32_t *d_qlen = nullptr, *d_rep_len = nullptr;
 	unsigned long long *d_mini_pos = nullptr;
 	int64_t seed_cap_mini = 0, n_mini_pos = 0;
+	int seed_max_n = -1, seed_max_n2 = -1; // largest reads the two configurations of the LDS sort take on this device
 	// profiling
 	bool prof = false;
 	std::vector<EventSet> pending;
@@ -325,11 +326,11 @@ static int compact_launch(chaindp_ctx *ctx, const chaindp_params_t *par)
 	if (rc) return rc;
 	if (!ctx->ran) { ctx->err = "compaction before chaindp_run"; return CHAINDP_ERR_ARG; }
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	if (!ctx->d_seeds) {
+	if (!ctx->d_id) {
 		const size_t na = (size_t)ctx->cap_anchors, nr = (size_t)ctx->cap_reads;
 		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_id, na * 4));
 		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_seeds_off, (nr + 1) * 8));
-		HIP_TRY(ctx, hipMalloc(&ctx->d_seeds, na * sizeof(chaindp_seed_t)));
+		if (!ctx->d_seeds) HIP_TRY(ctx, hipMalloc(&ctx->d_seeds, na * sizeof(chaindp_seed_t)));   // (seed collection may have made it already)
 		size_t flags_bytes = 0, blocks_bytes = 0;
 		chaindp::compact_scratch_bytes(ctx->cap_anchors, &flags_bytes, &blocks_bytes);
 		HIP_TRY(ctx, hipMalloc((void**)&ctx->cmp.block_cnt, blocks_bytes));
@@ -716,8 +717,18 @@ extern "C" int chaindp_collect_seeds(chaindp_ctx_t *ctx, const chaindp_index_t *
 		ctx->err = "the batch's seeds exceed the anchor capacity the context was created with";
 		return CHAINDP_ERR_CAPACITY;
 	}
+	// unsorted anchors go to the new_seed[] buffer (free at this point of a batch), the sort writes d_a
+	if (!ctx->d_seeds) HIP_TRY(ctx, hipMalloc(&ctx->d_seeds, (size_t)ctx->cap_anchors * sizeof(chaindp_seed_t)));
+	if (ctx->seed_max_n < 0) {
+		int lds_limit = 0;
+		HIP_TRY(ctx, hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device));
+		int m = 8192, m2 = 65024;
+		while (m > 0 && chaindp::seed_sort_lds_bytes(m, 32) > (size_t)lds_limit) m -= 512;
+		while (m2 > m && chaindp::seed_sort_lds_bytes(m2, 4) > (size_t)lds_limit) m2 -= 512;
+		ctx->seed_max_n = m; ctx->seed_max_n2 = m2;
+	}
 	HIP_TRY(ctx, chaindp::launch_seed_expand_sort(st, dix, flag, n_reads, n_mini, ctx->d_mini_off, ctx->d_mini, ctx->d_bid, ctx->d_qlen, ctx->seed,
-	                                              ctx->d_a, ctx->d_off, ctx->d_mini_pos));
+	                                              ctx->d_seeds, ctx->d_a, ctx->d_off, ctx->d_mini_pos, ctx->seed_max_n, ctx->seed_max_n2));
 	if (off) HIP_TRY(ctx, hipMemcpyAsync(off, ctx->d_off, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, st));
 	if (mini_pos_off) HIP_TRY(ctx, hipMemcpyAsync(mini_pos_off, ctx->d_mp_off, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, st));
 	if (rep_len && n_reads) HIP_TRY(ctx, hipMemcpyAsync(rep_len, ctx->d_rep_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));

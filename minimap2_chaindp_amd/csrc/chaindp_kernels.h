@@ -96,13 +96,16 @@ struct SeedScratch {                 // n = minimizers of the batch
 	void *stacks;                    // (max_anchors / 64 + 2 R + 4) x 12 B for the per-read sort
 };
 // phase 1: probe, scans, per-read offsets and rep_len; the host then reads off[n_reads] (capacity check) and runs
-// phase 2: expand (anchors in generation order, mini_pos) and the per-read radix_sort_128x
+// phase 2: expand (anchors in generation order into d_unsorted, mini_pos) and the per-read radix_sort_128x into d_a
 hipError_t launch_seed_collect(hipStream_t st, const SeedIndex &ix, int flag, int max_occ, int64_t n_reads, int64_t n_mini,
                                const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, const int32_t *d_qlen, SeedScratch sc,
                                void *d_a, int64_t *d_off, int64_t *d_mp_off, int32_t *d_rep_len, unsigned long long *d_mini_pos);
 hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag, int64_t n_reads, int64_t n_mini,
                                    const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, const int32_t *d_qlen, SeedScratch sc,
-                                   void *d_a, const int64_t *d_off, unsigned long long *d_mini_pos);
+                                   void *d_unsorted, void *d_a, const int64_t *d_off, unsigned long long *d_mini_pos, int max_n, int max_n2);
+// LDS bytes of the per-read sort for reads of up to max_n anchors with `workers` bucket tables; the host picks the largest
+// max_n (<= 8192, 32 workers) and max_n2 (<= 65535, 4 workers) that fit the device's LDS per workgroup
+size_t seed_sort_lds_bytes(int max_n, int workers);
 
 // zero-copy movement between device-visible (pinned) host buffers and HBM: chaindp_io.hip
 hipError_t launch_gather_reads(hipStream_t st, int64_t n_reads, const int64_t *d_off, const void *const *d_src, void *d_a);

@@ -199,13 +199,169 @@ __global__ __launch_bounds__(64) void k_seed_reads(int64_t n_reads, int64_t n_mi
 	rep_len[r] = rl + rep_en - rep_st;
 }
 
-__global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, const int64_t *__restrict__ off, ulonglong2 *__restrict__ a, BtRange *__restrict__ stacks)
+// Reads too large for the LDS sort below: the same procedure by one thread in global memory (slow, rare).
+__global__ __launch_bounds__(64) void k_seed_sort_big(int64_t n_reads, int max_n, const int64_t *__restrict__ off, const ulonglong2 *__restrict__ src,
+                                                      ulonglong2 *__restrict__ a, BtRange *__restrict__ stacks)
 {
 	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n_reads) return;
 	const int64_t b = off[r];
 	const int64_t n = off[r + 1] - b;
-	if (n > 1) bt_radix_128x(a + b, (int32_t)n, stacks + b / 64 + 2 * r);               // map.c:233
+	if (n <= max_n) return;
+	for (int64_t i = 0; i < n; ++i) a[b + i] = src[b + i];
+	bt_radix_128x(a + b, (int32_t)n, stacks + b / 64 + 2 * r);                           // map.c:233
+}
+
+// radix_sort_128x (ksort.h:101-151) of one read by one wave, in LDS, on (key, original index) pairs.  The reference's
+// in-place bucket permutation is sequential by nature (its order of equal keys depends on every swap before), so each
+// bucket range is still permuted by ONE lane, step by step as the reference does -- but disjoint ranges are
+// independent, so after the first one or two levels up to 32 lanes work on as many ranges at a time, the histograms and bucket
+// pointers live in LDS (16-bit: a read here has at most max_n <= 65535 anchors), and a level on which every key of
+// the range has the same digit is skipped (the reference's pass over it moves nothing).
+// LDS: keys[max_n] u64 | idx[max_n] u16 | workers x (head[256], tail[256]) u16 | two queues of SEED_Q ranges | 4 counters
+// (32 workers for reads of up to 8192 anchors; the same kernel with 4 workers takes reads of up to ~14 k).
+// A queue keeps its first SEED_QBIG slots for ranges of more than 64 anchors (at most max_n / 65 exist at a time, so
+// they always fit); small ranges that find the rest full are insertion-sorted on the spot by the lane that made them.
+struct SeedRange { uint16_t beg, end; uint16_t shift, pad; };
+#define SEED_QBIG 136
+#define SEED_Q (SEED_QBIG + 1024)
+
+__device__ __forceinline__ void seed_isort(uint64_t *key, uint16_t *idx, int beg, int end)    // ksort.h:107-117
+{
+	for (int i = beg + 1; i < end; ++i) {
+		if (key[i] < key[i - 1]) {
+			const uint64_t tk = key[i]; const uint16_t ti = idx[i];
+			int j = i;
+			while (j > beg && tk < key[j - 1]) { key[j] = key[j - 1]; idx[j] = idx[j - 1]; --j; }
+			key[j] = tk; idx[j] = ti;
+		}
+	}
+}
+
+// takes the reads with min_n < anchors <= max_n; `workers` lanes (a power of two <= 64) have bucket tables
+__global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int min_n, int max_n, int workers, const int64_t *__restrict__ off,
+                                                  const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ a)
+{
+	extern __shared__ uint64_t seed_lds[];
+	const int lane = threadIdx.x;
+	uint64_t *key = seed_lds;
+	uint16_t *idx = (uint16_t*)(key + max_n);
+	uint16_t *head = idx + max_n + (lane & (workers - 1)) * 512, *tail = head + 256;
+	SeedRange *qbase = (SeedRange*)(idx + max_n + workers * 512);
+	int *qn = (int*)(qbase + 2 * SEED_Q);                              // [parity][0 = big ranges, 1 = small ranges]
+	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+		const int64_t b = off[r];
+		const int64_t n64 = off[r + 1] - b;
+		if (n64 <= min_n || n64 > max_n) continue;
+		const int n = (int)n64;
+		__syncthreads();
+		// A sorted order is unique when all keys differ, and then any sort will do: try a bitonic network first (all 64
+		// lanes busy, ~0.1 ms) and keep its result unless two neighbours are equal; only reads with equal x go through the
+		// reference's procedure below (whose serial top levels take milliseconds).
+		int pow2 = 64;
+		while (pow2 < n) pow2 <<= 1;
+		{
+			// bitonic network in its all-ascending form (first step of a merge compares mirror positions), so that the
+			// virtual +inf padding behind the n real keys never has to move and needs no storage
+			for (int i = lane; i < n; i += 64) { key[i] = src[b + i].x; idx[i] = (uint16_t)i; }
+			if (lane == 0) qn[0] = 0;
+			__syncthreads();
+			for (int k = 2; k <= pow2; k <<= 1) {
+				for (int j = k >> 1; j > 0; j >>= 1) {
+					const bool mirror = j == k >> 1;
+					for (int t = lane; t < pow2 / 2; t += 64) {
+						const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+						const int l = mirror ? (i | (k - 1)) - (i & (j - 1)) : i | j;         // mirror: block end minus offset
+						if (l < n) {
+							const uint64_t ki = key[i], kl = key[l];
+							if (ki > kl) {
+								const uint16_t ti = idx[i]; idx[i] = idx[l]; idx[l] = ti;
+								key[i] = kl; key[l] = ki;
+							}
+						}
+					}
+					__syncthreads();
+				}
+			}
+			int ties = 0;
+			for (int i = lane; i + 1 < n; i += 64) ties |= key[i] == key[i + 1];
+			if (ties) qn[0] = 1;
+			__syncthreads();
+			const bool has_ties = qn[0] != 0;
+			__syncthreads();
+			if (!has_ties) {
+				for (int i = lane; i < n; i += 64) a[b + i] = src[b + idx[i]];
+				continue;
+			}
+		}
+		for (int i = lane; i < n; i += 64) { key[i] = src[b + i].x; idx[i] = (uint16_t)i; }
+		if (lane == 0) { qbase[0] = SeedRange{0, (uint16_t)n, 56, 0}; qn[0] = 1; qn[1] = 0; qn[2] = 0; qn[3] = 0; }
+		__syncthreads();
+		for (int which = 0;; which ^= 1) {
+			SeedRange *cur = qbase + which * SEED_Q, *nxt = qbase + (which ^ 1) * SEED_Q;
+			int *ncnt = qn + 2 * (which ^ 1);
+			const int n_big = qn[2 * which], n_small = min(qn[2 * which + 1], SEED_Q - SEED_QBIG);
+			if (n_big + n_small == 0) break;
+			if (lane < workers) {
+				for (int w = lane; w < n_big + n_small; w += workers) {
+					const SeedRange rg = w < n_big ? cur[w] : cur[SEED_QBIG + (w - n_big)];
+					const int rb = rg.beg, re = rg.end, len = re - rb, sh = rg.shift;
+					if (len <= 64) { seed_isort(key, idx, rb, re); continue; }           // ksort.h:143,148
+					for (int d = 0; d < 256; ++d) tail[d] = 0;
+					for (int q = rb; q < re; ++q) ++tail[key[q] >> sh & 0xff];           // ksort.h:126
+					const int d0 = (int)(key[rb] >> sh & 0xff);
+					if (tail[d0] == len) {                                               // one bucket: the pass moves nothing
+						if (sh) nxt[atomicAdd(&ncnt[0], 1)] = SeedRange{(uint16_t)rb, (uint16_t)re, (uint16_t)(sh > 8 ? sh - 8 : 0), 0};
+						continue;
+					}
+					int acc = rb;
+					for (int d = 0; d < 256; ++d) { head[d] = (uint16_t)acc; acc += tail[d]; tail[d] = (uint16_t)acc; }
+					for (int d = 0; d < 256;) {                                          // ksort.h:129-141, cycle-leader permutation
+						if (head[d] != tail[d]) {
+							int l = (int)(key[head[d]] >> sh & 0xff);
+							if (l != d) {
+								uint64_t ck = key[head[d]], sk; uint16_t ci = idx[head[d]], si;
+								do {
+									sk = ck; si = ci;
+									const int hp = head[l];
+									ck = key[hp]; ci = idx[hp];
+									key[hp] = sk; idx[hp] = si;
+									head[l] = (uint16_t)(hp + 1);
+									l = (int)(ck >> sh & 0xff);
+								} while (l != d);
+								const int hp = head[d];
+								key[hp] = ck; idx[hp] = ci;
+								head[d] = (uint16_t)(hp + 1);
+							} else ++head[d];
+						} else ++d;
+					}
+					if (sh) {                                                            // ksort.h:143-149: sub-ranges become work items
+						const int next = sh > 8 ? sh - 8 : 0;
+						int sb = rb;
+						for (int d = 0; d < 256; ++d) {
+							const int se = tail[d];
+							if (se - sb > 64) nxt[atomicAdd(&ncnt[0], 1)] = SeedRange{(uint16_t)sb, (uint16_t)se, (uint16_t)next, 0};
+							else if (se - sb > 1) {
+								const int k = atomicAdd(&ncnt[1], 1);
+								if (k < SEED_Q - SEED_QBIG) nxt[SEED_QBIG + k] = SeedRange{(uint16_t)sb, (uint16_t)se, (uint16_t)next, 0};
+								else seed_isort(key, idx, sb, se);
+							}
+							sb = se;
+						}
+					}
+				}
+			}
+			__syncthreads();
+			if (lane == 0) { qn[2 * which] = 0; qn[2 * which + 1] = 0; }
+			__syncthreads();
+		}
+		for (int i = lane; i < n; i += 64) a[b + i] = src[b + idx[i]];
+	}
+}
+
+size_t seed_sort_lds_bytes(int max_n, int workers)
+{
+	return (((size_t)max_n * 10 + 7) & ~(size_t)7) + (size_t)workers * 512 * 2 + 2 * (size_t)SEED_Q * sizeof(SeedRange) + 16;
 }
 
 hipError_t launch_seed_collect(hipStream_t st, const SeedIndex &ix, int flag, int max_occ, int64_t n_reads, int64_t n_mini,
@@ -226,14 +382,21 @@ hipError_t launch_seed_collect(hipStream_t st, const SeedIndex &ix, int flag, in
 
 hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag, int64_t n_reads, int64_t n_mini,
                                    const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, const int32_t *d_qlen, SeedScratch sc,
-                                   void *d_a, const int64_t *d_off, unsigned long long *d_mini_pos)
+                                   void *d_unsorted, void *d_a, const int64_t *d_off, unsigned long long *d_mini_pos, int max_n, int max_n2)
 {
 	if (n_mini > 0) {
 		hipLaunchKernelGGL(k_seed_expand, dim3((unsigned)((n_mini + 255) / 256)), dim3(256), 0, st, ix, flag, n_reads, n_mini, d_mini_off,
-		                   (const ulonglong2*)d_mini, d_bid, d_qlen, sc.kept, sc.used, sc.src, sc.mstate, (ulonglong2*)d_a, d_mini_pos);
+		                   (const ulonglong2*)d_mini, d_bid, d_qlen, sc.kept, sc.used, sc.src, sc.mstate, (ulonglong2*)d_unsorted, d_mini_pos);
 	}
-	if (n_reads > 0)
-		hipLaunchKernelGGL(k_seed_sort, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, st, n_reads, d_off, (ulonglong2*)d_a, (BtRange*)sc.stacks);
+	if (n_reads > 0) {
+		// the LDS sort takes reads of up to max_n anchors (what fits the device's LDS per workgroup); anything larger goes
+		// to the one-thread version
+		const unsigned grid = (unsigned)(n_reads < 256 * 8 ? n_reads : 256 * 8);
+		if (max_n > 0) hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(64), seed_sort_lds_bytes(max_n, 32), st, n_reads, 0, max_n, 32, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a);
+		if (max_n2 > max_n) hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(64), seed_sort_lds_bytes(max_n2, 4), st, n_reads, max_n, max_n2, 4, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a);
+		hipLaunchKernelGGL(k_seed_sort_big, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, st, n_reads, max_n2 > max_n ? max_n2 : max_n, d_off, (const ulonglong2*)d_unsorted,
+		                   (ulonglong2*)d_a, (BtRange*)sc.stacks);
+	}
 	return hipGetLastError();
 }
 
