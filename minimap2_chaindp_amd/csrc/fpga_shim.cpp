@@ -19,6 +19,7 @@
 #include <map>
 #include <mutex>
 #include <thread>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 #include "../../include/chaindp_fpga.h"
@@ -79,8 +80,8 @@ struct Service {
 	unsigned long max_inflight = 1ul << 30;
 	// fpga_set_params (main.c:243)
 	int bw = 500, is_cdna = 0, max_skip = 25, min_sc = 40, flag = 0, max_occ = 0;
-	chaindp::IndexImage index;         // fpga_load_index (main.c:201-204): what the host-side seed collection looks seeds up in
-	int seed_threads = 8;              // host threads a service thread spreads one batch's seed collection over
+	chaindp::IndexImage index;         // fpga_load_index (main.c:201-204): the image minimizer packets are looked up in
+	uint64_t index_gen = 0;            // bumped by every fpga_load_index call: service threads refresh their device copy
 	PinnedPool pool;
 	std::mutex mu;
 	std::condition_variable cv_submit, cv_result;
@@ -121,9 +122,11 @@ void service_loop(int device)
 	if (!ctx) { fprintf(stderr, "[chaindp-fpga] %s\n", chaindp_last_error(nullptr)); fail_hard("cannot create a device context"); }
 	std::vector<Submitted> pk;
 	std::vector<ReadRef> reads;
+	chaindp_index_t *dev_index = nullptr;          // this context's copy of the index image, for minimizer packets
+	uint64_t dev_index_gen = 0;
 	for (;;) {
 		pk.clear(); reads.clear();
-		int bw, is_cdna, max_skip, min_sc, sflag, max_occ, seed_threads;
+		int bw, is_cdna, max_skip, min_sc, sflag, max_occ;
 		bool have_index;
 		{
 			std::unique_lock<std::mutex> lk(g.mu);
@@ -132,12 +135,22 @@ void service_loop(int device)
 			int64_t anchors_est = 0;
 			while (!g.submit_q.empty() && (int)pk.size() < g.max_packets) {
 				const Submitted s = g.submit_q.front();
-				if (!pk.empty() && anchors_est + (int64_t)(s.size / 16) > cap_anchors) break;
-				anchors_est += s.size / 16;
+				// anchors of the packet: its payload for anchor packets; for minimizer packets a guess (a minimizer has a
+				// handful of hits below mid_occ), checked for real after the lookup
+				const int64_t est = (int64_t)(s.size / 16) * (((const chaindp_pkt_hdr_t*)s.buf)->type == CHAINDP_PKT_MINIMIZERS ? 4 : 1);
+				if (!pk.empty() && anchors_est + est > cap_anchors) break;
+				anchors_est += est;
 				pk.push_back(s); g.submit_q.pop_front();
 			}
 			bw = g.bw; is_cdna = g.is_cdna; max_skip = g.max_skip; min_sc = g.min_sc;
-			sflag = g.flag; max_occ = g.max_occ; have_index = g.index.complete(); seed_threads = g.seed_threads;
+			sflag = g.flag; max_occ = g.max_occ; have_index = g.index.complete();
+			if (have_index && (!dev_index || dev_index_gen != g.index_gen)) {       // (re)load this context's copy of the index image
+				if (dev_index) chaindp_index_destroy(dev_index);
+				dev_index = chaindp_index_create(device, g.index.blob(0).data(), g.index.blob(0).size(), g.index.blob(1).data(), g.index.blob(1).size(),
+				                                 g.index.blob(2).data(), g.index.blob(2).size(), g.index.blob(3).data(), g.index.blob(3).size());
+				if (!dev_index) { fprintf(stderr, "[chaindp-fpga] %s\n", chaindp_last_error(nullptr)); fail_hard("cannot load the index image onto the device"); }
+				dev_index_gen = g.index_gen;
+			}
 		}
 		// ---- parse (map.c:484-568 walks the packet the same way)
 		for (size_t k = 0; k < pk.size(); ++k) {
@@ -161,44 +174,12 @@ void service_loop(int device)
 				reads.push_back(rr);
 			}
 		}
-		// ---- minimizer packets: the reference's device did the seed lookup (map.c:523 inside fpga_work); here the shim's
-		// host threads do, over the index image of fpga_load_index, into one pinned staging buffer per batch
-		void *seed_stage = nullptr;
-		{
-			std::vector<size_t> todo;
-			for (size_t r = 0; r < reads.size(); ++r) if (reads[r].mini) todo.push_back(r);
-			if (!todo.empty()) {
-				std::vector<std::vector<chaindp::U128>> got(todo.size());
-				auto work = [&](size_t t0, size_t step) {
-					for (size_t t = t0; t < todo.size(); t += step) {
-						ReadRef &rr = reads[todo[t]];
-						chaindp::collect_seed_hits(g.index, sflag, max_occ, (const chaindp::U128*)rr.mini, (size_t)rr.task->seednum,
-						                           rr.task->bid, rr.task->qlensum, got[t], &rr.rep_len, rr.mini_pos);
-					}
-				};
-				const size_t nt = std::min<size_t>((size_t)(seed_threads > 1 ? seed_threads : 1), todo.size());
-				std::vector<std::thread> th;
-				for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t, nt);
-				work(0, nt);
-				for (auto &x : th) x.join();
-				size_t tot = 0;
-				for (auto &v : got) tot += v.size();
-				seed_stage = g.pool.get((tot ? tot : 1) * sizeof(chaindp_anchor_t));
-				if (!seed_stage) fail_hard("out of pinned memory");
-				chaindp_anchor_t *dst = (chaindp_anchor_t*)seed_stage;
-				for (size_t t = 0; t < todo.size(); ++t) {
-					ReadRef &rr = reads[todo[t]];
-					if (!got[t].empty()) memcpy(dst, got[t].data(), got[t].size() * sizeof(chaindp_anchor_t));
-					rr.anchors = dst; rr.n_anchors = (int64_t)got[t].size();
-					dst += got[t].size();
-				}
-			}
-		}
-		// ---- group by (gap_ref, gap_qry): one device batch per distinct pair (one pair in practice)
-		std::map<std::pair<int, int>, std::vector<size_t>> groups;
+		// ---- group by payload kind and (gap_ref, gap_qry): one device batch per distinct combination (one in practice)
+		std::map<std::tuple<int, int, int>, std::vector<size_t>> groups;
 		for (size_t r = 0; r < reads.size(); ++r)
-			if (reads[r].on_device) groups[{reads[r].task->gap_ref, reads[r].task->gap_qry}].push_back(r);
+			if (reads[r].on_device) groups[std::make_tuple(reads[r].mini ? 1 : 0, reads[r].task->gap_ref, reads[r].task->gap_qry)].push_back(r);
 		const bool single_group = groups.size() <= 1;
+		bool built = false;
 		std::vector<int64_t> n_a(reads.size(), 0);
 		std::vector<const chaindp_seed_t*> seed_src(reads.size(), nullptr);   // multi-group only: staged new_seed[]
 		std::vector<void*> group_stage;
@@ -262,8 +243,9 @@ void service_loop(int device)
 
 		for (auto &kv : groups) {
 			const std::vector<size_t> &idx = kv.second;
+			const bool from_minimizers = std::get<0>(kv.first) != 0;
 			chaindp_params_t par;
-			par.max_dist_x = kv.first.first; par.max_dist_y = kv.first.second; par.bw = bw; par.max_skip = max_skip;
+			par.max_dist_x = std::get<1>(kv.first); par.max_dist_y = std::get<2>(kv.first); par.bw = bw; par.max_skip = max_skip;
 			par.min_sc = min_sc; par.is_cdna = is_cdna; par.n_segs = 1;
 			std::vector<int64_t> off(idx.size() + 1, 0);
 			std::vector<const chaindp_anchor_t*> ptrs(idx.size());
@@ -275,14 +257,45 @@ void service_loop(int device)
 				nseg[k] = rr.task->n_segs;
 			}
 			std::vector<int64_t> soff(idx.size() + 1, 0);
-			// the packets are pinned driver buffers: one gather kernel pulls every read's anchors over PCIe
-			int rc = chaindp_upload_gather_ex(ctx, (int64_t)idx.size(), off.data(), ptrs.data(), nseg.data(), 1);
+			int rc;
+			if (from_minimizers) {
+				// the reference's device did the seed lookup (map.c:523 inside fpga_work): the read's minimizers go to the GPU,
+				// which looks them up in the index image, expands, sorts (chaindp_seed.hip) and leaves the anchors in HBM
+				std::vector<int64_t> moff(idx.size() + 1, 0), mpoff(idx.size() + 1, 0);
+				std::vector<uint32_t> bids(idx.size());
+				std::vector<int32_t> qlens(idx.size()), rlen(idx.size());
+				for (size_t k = 0; k < idx.size(); ++k) moff[k + 1] = moff[k] + reads[idx[k]].task->seednum;
+				std::vector<chaindp_anchor_t> mini((size_t)moff[idx.size()]);
+				for (size_t k = 0; k < idx.size(); ++k) {
+					const ReadRef &rr = reads[idx[k]];
+					if (rr.task->seednum) memcpy(mini.data() + moff[k], rr.mini, (size_t)rr.task->seednum * sizeof(chaindp_anchor_t));
+					bids[k] = rr.task->bid; qlens[k] = rr.task->qlensum;
+				}
+				rc = chaindp_collect_seeds(ctx, dev_index, sflag, max_occ, (int64_t)idx.size(), moff.data(), mini.data(), bids.data(), qlens.data(),
+				                           nseg.data(), off.data(), rlen.data(), mpoff.data());
+				std::vector<uint64_t> mp((size_t)(rc == CHAINDP_OK ? mpoff[idx.size()] : 0) + 1);
+				if (rc == CHAINDP_OK) rc = chaindp_download_mini_pos(ctx, mp.data());
+				if (rc == CHAINDP_OK) for (size_t k = 0; k < idx.size(); ++k) {
+					ReadRef &rr = reads[idx[k]];
+					rr.n_anchors = off[k + 1] - off[k]; rr.rep_len = rlen[k];
+					rr.mini_pos.assign(mp.begin() + mpoff[k], mp.begin() + mpoff[k + 1]);
+				}
+			} else {
+				// the packets are pinned driver buffers: one gather kernel pulls every read's anchors over PCIe
+				rc = chaindp_upload_gather_ex(ctx, (int64_t)idx.size(), off.data(), ptrs.data(), nseg.data(), 1);
+			}
+			if (from_minimizers && rc == CHAINDP_ERR_CAPACITY) {
+				// more seeds than one device batch holds: hand these reads back the way the reference's device reports
+				// "cannot do it" (err_flag = 1, map.c:933-944) instead of failing the run
+				for (size_t k = 0; k < idx.size(); ++k) { reads[idx[k]].on_device = false; reads[idx[k]].mini_pos.clear(); }
+				continue;
+			}
 			if (rc == CHAINDP_OK) rc = chaindp_run(ctx, &par);
 			if (rc == CHAINDP_OK) rc = chaindp_compact_offsets(ctx, &par, soff.data());
 			if (rc != CHAINDP_OK) { fprintf(stderr, "[chaindp-fpga] %s\n", chaindp_last_error(ctx)); fail_hard("device batch failed"); }
 			for (size_t k = 0; k < idx.size(); ++k) n_a[idx[k]] = soff[k + 1] - soff[k];
 			if (single_group) {
-				build_packets();
+				build_packets(); built = true;
 				std::vector<chaindp_seed_t*> dst(idx.size());
 				for (size_t k = 0; k < idx.size(); ++k) dst[k] = seed_dst[idx[k]];
 				rc = chaindp_scatter_seeds(ctx, (int64_t)idx.size(), dst.data());      // device writes into the result packets
@@ -300,9 +313,8 @@ void service_loop(int device)
 			std::lock_guard<std::mutex> lk(g.mu);
 			g.stats[3] += 1;
 		}
-		if (!single_group || groups.empty()) build_packets();
+		if (!built) build_packets();
 		for (void *s : group_stage) g.pool.put(s);
-		if (seed_stage) g.pool.put(seed_stage);
 		{
 			std::lock_guard<std::mutex> lk(g.mu);
 			for (size_t k = 0; k < pk.size(); ++k) { g.inflight_bytes -= pk[k].size; g.pool.put(pk[k].buf); }
@@ -311,6 +323,7 @@ void service_loop(int device)
 		}
 		g.cv_result.notify_all();
 	}
+	if (dev_index) chaindp_index_destroy(dev_index);
 	chaindp_destroy(ctx);
 }
 
@@ -383,6 +396,7 @@ extern "C" void fpga_load_index(void *addr, int size, int type)
 	if (!addr || size <= 0) return;
 	std::lock_guard<std::mutex> lk(g.mu);
 	g.index.append(type, addr, (size_t)size);
+	++g.index_gen;
 }
 
 extern "C" int chaindp_fpga_collect_seeds(uint32_t bid, int qlen, const chaindp_anchor_t *mini, int64_t n_mini,
