@@ -20,9 +20,9 @@
  * and parsed at map.c:484-568 (device side) / map.c:918-931 (host side).  Two task payloads are served
  * (SURVEY 8b "Build's boundary"):
  *   type == 3 (the reference's packets, unmodified): payload of each task = seednum x mm128_t MINIMIZERS.  The
- *       FPGA looked the seeds up in its own index image; here the shim's host threads do (collect_seed_hits,
- *       map.c:187-236, over the image received through fpga_load_index), and the sorted anchors go to the
- *       GPU.  Without a complete index image every read of such a packet is answered with err_flag = 1 and
+ *       FPGA looked the seeds up in its own index image; here the GPU does (collect_seed_hits, map.c:187-236,
+ *       over the image received through fpga_load_index: chaindp_collect_seeds), and chains the anchors where
+ *       they are.  Without a complete index image every read of such a packet is answered with err_flag = 1 and
  *       no payload, the reference's own "device cannot handle it" signal -- the host then recomputes that
  *       read on the CPU (map.c:933-944).
  *   type == CHAINDP_PKT_ANCHORS : payload of each task = seednum x mm128_t anchors, sorted by x (what
@@ -103,8 +103,8 @@ void chaindp_fpga_configure(int n_gpus, int max_packets_per_batch, unsigned long
 /* Counters since fpga_init: st[0] packets, st[1] reads, st[2] anchors, st[3] device batches,
  * st[4] reads answered err_flag=1. */
 void chaindp_fpga_stats(int64_t st[5]);
-/* The shim's host-side seed collection for minimizer packets (type 3), callable on its own (no GPU involved; tests
- * and tools): collect_seed_hits of the reference (map.c:187-236) for one read, over the index image received
+/* A host-side statement of the seed collection the GPU does for minimizer packets (type 3), callable on its own (no
+ * GPU involved; tests and tools): collect_seed_hits of the reference (map.c:187-236) for one read, over the index image received
  * through fpga_load_index (types 4..7, index.c:603-720) with the flag / max_occ of fpga_set_params (main.c:243).
  * mini = the read's minimizers as collect_minimizers leaves them (map.c:352), bid / qlen as in collect_task_t.
  * Writes up to cap_anchors sorted anchors and *n_anchors (the count needed, also when it exceeds the capacity),

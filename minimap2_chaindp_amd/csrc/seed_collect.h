@@ -1,10 +1,10 @@
-// seed_collect.h -- host-side seed collection for unmodified minimizer packets (reference type 3).
+// seed_collect.h -- the index image of the packet shim, and a host-side statement of seed collection over it.
 //
 // The reference's FPGA received minimizers and looked the seeds up itself, in an index image the host streams to
-// it through fpga_load_index (index.c:603-720 builds the image, main.c:201-204 sends it as types 4..7).  SURVEY
-// section 8(b) keeps seed collection on the host in this build: the shim's worker threads run the equivalent of
-// collect_seed_hits (map.c:112-236) over that same image and hand sorted anchors to the GPU.  This is host code
-// of the packet shim, not a CPU path of the chaining DP.
+// it through fpga_load_index (index.c:603-720 builds the image, main.c:201-204 sends it as types 4..7).  The
+// shim keeps the image (IndexImage) and has the GPU do that lookup (chaindp_seed.hip).  collect_seed_hits below is
+// the same computation on the host (map.c:112-236), exported as chaindp_fpga_collect_seeds for tools and for the
+// CPU test tier, where it is pinned against the reference's own results; the product's packet path does not use it.
 #ifndef CHAINDP_SEED_COLLECT_H
 #define CHAINDP_SEED_COLLECT_H
 
