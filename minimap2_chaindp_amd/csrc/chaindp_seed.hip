@@ -10,8 +10,9 @@
 //                  generation order, and its mini_pos entry
 //   k_seed_reads   thread per read: anchor / mini_pos offsets of the read and rep_len (the interval merge of
 //                  map.c:127-133 is sequential in the minimizers, 2-3 k steps)
-//   k_seed_sort    thread per read: radix_sort_128x exactly as the reference runs it (chaindp_rsort.h); the order of
-//                  equal x is input to the chaining DP
+//   k_seed_sort    wave per read, in LDS: the order radix_sort_128x (ksort.h:101-151) gives equal x is input to the
+//                  chaining DP, so a read with equal keys is sorted by the reference's procedure step by step; a
+//                  read without (the common case) by a bitonic network.  k_seed_sort_big: reads too large for LDS.
 // Image layout: see csrc/seed_collect.h (the host-side statement of the same lookup, pinned on the CPU tier).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
