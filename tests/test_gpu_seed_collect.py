@@ -74,3 +74,95 @@ def test_gpu_seed_collection_at_scale():
               f"-> {len(a) / dt / 1e6:.1f} M anchors/s")
         assert np.array_equal(off, g["a_off"]) and np.array_equal(a, g["anchors"])
         assert np.array_equal(rep_len, g["rep_len"]) and np.array_equal(mp, g["mini_pos"])
+
+
+def _build_image(rng, n_keys, max_cnt, b_bits=6):
+    """A synthetic index image in the reference's FPGA layout (index.c:603-720): random minimizers with 1..max_cnt positions,
+    hashed into 2^b_bits buckets with khash's own probing (khash.h:218-231).  Returns (blobs, minimizer values)."""
+    keys = rng.choice(1 << 34, size=n_keys, replace=False).astype(np.uint64) + np.uint64(1)
+    buckets = [[] for _ in range(1 << b_bits)]
+    for m in keys:
+        buckets[int(m) & ((1 << b_bits) - 1)].append(int(m))
+    B, H, V, Pa = bytearray(), bytearray(), bytearray(), bytearray()
+    allh = allp = 0
+    for bk in buckets:
+        if not bk:
+            B += (0).to_bytes(16, "little")
+            continue
+        nb = 4
+        while nb < 2 * len(bk):
+            nb <<= 1
+        slots_k, slots_v, used, p_local = [0] * nb, [0] * nb, [False] * nb, []
+        for m in bk:
+            cnt = int(rng.integers(1, max_cnt + 1))
+            pos = [int(rng.integers(0, 1 << 20)) << 43 | int(rng.integers(0, 1 << 21)) << 22 | int(rng.integers(0, 2)) << 21 | int(rng.integers(0, 1 << 10))
+                   for _ in range(cnt)]
+            key = (m >> b_bits) << 1
+            i, step = (key >> 1) & (nb - 1), 0
+            while used[i]:
+                step += 1
+                i = (i + step) & (nb - 1)
+            used[i] = True
+            if cnt == 1:
+                slots_k[i], slots_v[i] = key | 1, pos[0]
+            else:
+                slots_k[i], slots_v[i] = key, len(p_local) << 32 | cnt
+                p_local += pos
+        tmp_nb = (nb + 7) & ~7
+        B += (((allp & 0xff) << 56) | (nb << 24)).to_bytes(8, "little") + ((allh << 28) | (allp >> 8)).to_bytes(8, "little")
+        flags = [0] * max(1, nb >> 4)
+        for i in range(nb):
+            if not used[i]:
+                flags[i >> 4] |= 2 << ((i & 15) << 1)                 # "empty" (khash.h:166)
+        for g0 in range(0, tmp_nb, 8):
+            H += (flags[g0 >> 4] & 0xffffffff).to_bytes(4, "little")
+            for i in range(g0, g0 + 8):
+                H += ((slots_k[i] if i < nb else 0) & 0xffffffffffff).to_bytes(6, "little")
+                V += ((slots_v[i] if i < nb else 0)).to_bytes(8, "little")
+            H += bytes(12)
+        for x in p_local:
+            Pa += x.to_bytes(8, "little")
+        allh += tmp_nb
+        allp += len(p_local)
+    blobs = [np.frombuffer(bytes(x), np.uint8).copy() for x in (B, H, V, Pa)]
+    return blobs, keys
+
+
+@pytest.mark.parametrize("seed,max_cnt,n_mini,rep_pct", [(1, 3, 400, 0), (2, 6, 900, 20), (3, 40, 500, 30), (4, 12, 2500, 40), (5, 90, 400, 25), (6, 90, 1500, 35)])
+def test_gpu_seed_collection_against_host_statement_on_synthetic_images(seed, max_cnt, n_mini, rep_pct):
+    """Random index images and minimizer lists with many repeated minimizers (equal x in the anchors) and reads of a few
+    hundred to > 14 k anchors: all three sort paths (bitonic, the reference's procedure in LDS with 32 / 4 bucket tables, one
+    thread in global memory).  Expected values come from the host statement (csrc/seed_collect.cpp), itself pinned against
+    the reference on the CPU tier."""
+    from minimap2_chaindp_amd import fpga
+    rng = np.random.default_rng(seed)
+    blobs, keys = _build_image(rng, 3000, max_cnt)
+    n_reads, flag, max_occ = 6, int(rng.choice([0, 3, 0x100000])), int(max_cnt * 3 // 4 + 2)
+    mini, mini_off, bid, qlen = [], [0], [], []
+    for r in range(n_reads):
+        nm = int(n_mini * (r + 1) / n_reads)
+        pool = keys[rng.integers(0, len(keys), max(2, nm * (100 - rep_pct) // 100))]
+        pick = pool[rng.integers(0, len(pool), nm)]
+        absent = rng.random(nm) < 0.05
+        pick = np.where(absent, pick + np.uint64(1 << 36), pick)
+        span = rng.integers(1, 29, nm).astype(np.uint64)
+        qp = np.sort(rng.integers(0, 30000, nm)).astype(np.uint64)
+        x = pick << np.uint64(8) | span
+        y = (qp << np.uint64(1)) | rng.integers(0, 2, nm).astype(np.uint64)
+        mini.append(np.stack([x, y], 1)); mini_off.append(mini_off[-1] + nm)
+        bid.append(int(rng.integers(0, 1 << 10)) | (int(rng.integers(0, 2)) << 31)); qlen.append(30100)
+    mini = np.concatenate(mini)
+    fpga.load_index(blobs)
+    fpga.lib().fpga_set_params(500, 0, 25, 40, flag, max_occ)
+    exp = [fpga.collect_seeds(bid[r], qlen[r], mini[mini_off[r]:mini_off[r + 1]]) for r in range(n_reads)]
+    fpga.lib().fpga_finalize()
+    with chaindp.Device(0, max_anchors=1 << 21, max_reads=64) as d:
+        ix = d.load_index(blobs)
+        off, a, rep_len, mpo, mp = d.collect_seeds(ix, flag, max_occ, np.array(mini_off, np.int64), mini, np.array(bid, np.uint32), np.array(qlen, np.int32))
+    sizes = [len(e[0]) for e in exp]
+    assert list(np.diff(off)) == sizes, (sizes, list(np.diff(off)))
+    for r in range(n_reads):
+        assert np.array_equal(a[off[r]:off[r + 1]], exp[r][0]), (seed, r, sizes[r], "anchors")
+        assert rep_len[r] == exp[r][1] and np.array_equal(mp[mpo[r]:mpo[r + 1]], exp[r][2]), (seed, r)
+    ties = sum(int((np.diff(e[0][:, 0]) == 0).sum()) for e in exp if len(e[0]) > 1)
+    print(f"\nseed {seed}: anchors per read {sizes}, equal-x pairs {ties}")
