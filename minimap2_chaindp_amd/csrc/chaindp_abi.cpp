@@ -707,8 +707,8 @@ extern "C" int chaindp_collect_seeds(chaindp_ctx_t *ctx, const chaindp_index_t *
 	dix.B = ix->blob[0]; dix.H = ix->blob[1]; dix.V = ix->blob[2]; dix.P = ix->blob[3];
 	dix.nB = ix->bytes[0]; dix.nH = ix->bytes[1]; dix.nV = ix->bytes[2]; dix.nP = ix->bytes[3];
 	dix.b_bits = ix->b_bits;
-	HIP_TRY(ctx, chaindp::launch_seed_collect(st, dix, flag, max_occ, n_reads, n_mini, ctx->d_mini_off, ctx->d_mini, ctx->d_bid, ctx->d_qlen,
-	                                          ctx->seed, ctx->d_a, ctx->d_off, ctx->d_mp_off, ctx->d_rep_len, ctx->d_mini_pos));
+	HIP_TRY(ctx, chaindp::launch_seed_collect(st, dix, flag, max_occ, n_reads, n_mini, ctx->d_mini_off, ctx->d_mini, ctx->d_bid, ctx->seed,
+	                                          ctx->d_off, ctx->d_mp_off, ctx->d_rep_len));
 	unsigned long long totals[2] = {0, 0};
 	HIP_TRY(ctx, hipMemcpyAsync(totals, ctx->seed.totals, 16, hipMemcpyDeviceToHost, st));
 	HIP_TRY(ctx, hipStreamSynchronize(st));

@@ -98,8 +98,8 @@ struct SeedScratch {                 // n = minimizers of the batch
 // phase 1: probe, scans, per-read offsets and rep_len; the host then reads off[n_reads] (capacity check) and runs
 // phase 2: expand (anchors in generation order into d_unsorted, mini_pos) and the per-read radix_sort_128x into d_a
 hipError_t launch_seed_collect(hipStream_t st, const SeedIndex &ix, int flag, int max_occ, int64_t n_reads, int64_t n_mini,
-                               const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, const int32_t *d_qlen, SeedScratch sc,
-                               void *d_a, int64_t *d_off, int64_t *d_mp_off, int32_t *d_rep_len, unsigned long long *d_mini_pos);
+                               const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, SeedScratch sc,
+                               int64_t *d_off, int64_t *d_mp_off, int32_t *d_rep_len);
 hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag, int64_t n_reads, int64_t n_mini,
                                    const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, const int32_t *d_qlen, SeedScratch sc,
                                    void *d_unsorted, void *d_a, const int64_t *d_off, unsigned long long *d_mini_pos, int max_n, int max_n2);

@@ -366,8 +366,8 @@ size_t seed_sort_lds_bytes(int max_n, int workers)
 }
 
 hipError_t launch_seed_collect(hipStream_t st, const SeedIndex &ix, int flag, int max_occ, int64_t n_reads, int64_t n_mini,
-                               const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, const int32_t *d_qlen, SeedScratch sc,
-                               void *d_a, int64_t *d_off, int64_t *d_mp_off, int32_t *d_rep_len, unsigned long long *d_mini_pos)
+                               const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, SeedScratch sc,
+                               int64_t *d_off, int64_t *d_mp_off, int32_t *d_rep_len)
 {
 	hipError_t e;
 	if (n_mini > 0) {
