@@ -118,7 +118,43 @@ def synthetic_fasta():
     return "/tmp/seedgold_tgt.fa", "/tmp/seedgold_reads.fa"
 
 
+def big_fasta():
+    """600 noisy 8 kb reads of a 150 kb random genome (coverage 32), both strands: the all-vs-all batch of
+    tests/golden/_big/big_avaont.npz (42 MB, git-ignored; travels to the GPU box with the snapshot)."""
+    rnd = random.Random(5)
+    g = "".join(rnd.choice("ACGT") for _ in range(150000))
+
+    def mutate(s, rate):
+        out = []
+        for c in s:
+            r = rnd.random()
+            if r < rate / 3:
+                continue
+            if r < 2 * rate / 3:
+                out.append(rnd.choice("ACGT"))
+            elif r < rate:
+                out.append(c); out.append(rnd.choice("ACGT"))
+            else:
+                out.append(c)
+        return "".join(out)
+
+    reads = []
+    for i in range(600):
+        st = rnd.randrange(0, len(g) - 8000)
+        s = mutate(g[st:st + 8000], 0.08)
+        reads.append(("r%04d" % i, s[::-1].translate(str.maketrans("ACGT", "TGCA")) if i % 2 else s))
+    open("/tmp/seedgold_big.fa", "w").write("".join(">%s\n%s\n" % x for x in reads))
+    return "/tmp/seedgold_big.fa"
+
+
 if __name__ == "__main__":
+    import sys
+    if "--big" in sys.argv:                      # the large, git-ignored dump for the at-scale test and tools/shim_minimizer_bench.py
+        OUT = os.path.join(HERE, "_big")
+        os.makedirs(OUT, exist_ok=True)
+        fa = big_fasta()
+        make("big_avaont", "ava-ont", fa, fa)
+        sys.exit(0)
     os.makedirs(OUT, exist_ok=True)
     t = os.path.join(REF, "test")
     make("mt_orang_vs_human_mapont", "map-ont", f"{t}/MT-human.fa", f"{t}/MT-orang.fa")
