@@ -158,6 +158,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(total),
                 "algorithmic_bytes_per_anchor": ALGO_BYTES_PER_ANCHOR, "anchors_per_launch": total,
                 "avg_launch_ms": dp_ms,
+                # what actually bounds the kernel: vector-instruction issue.  Instruction count
+                # from the committed PMC pass of this batch, duration live; peak = 1024 SIMDs x 2.4 GHz / 4 cycles.
+                "valu_issue": measured_valu_issue(total, dp_ms),
             },
             "kernel_ms": {"prepass": pre_ms, "chain_dp": dp_ms, "compact": cmp_ms},
             "host": {"generate_s": t_gen, "upload_s": t_up, "upload_GBps": total * 16 / t_up / 1e9 if t_up > 0 else None},
@@ -241,6 +244,20 @@ def measured_traffic(anchors_per_launch):
         t = json.load(open(path))
         if t.get("anchors_per_launch") == anchors_per_launch:
             return t["hbm_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
+def measured_valu_issue(anchors_per_launch, dp_ms):
+    path = os.path.join(ROOT, "profiles", "latest_traffic.json")
+    try:
+        t = json.load(open(path))
+        if t.get("anchors_per_launch") == anchors_per_launch and t.get("valu_insts_per_launch") and dp_ms > 0:
+            peak = 256 * 4 * 2.4e9 / 4 / 1e9                                     # G wave-instructions/s
+            ach = t["valu_insts_per_launch"] / (dp_ms * 1e-3) / 1e9
+            return {"insts_per_anchor": t["valu_insts_per_launch"] / anchors_per_launch, "achieved": ach, "peak": peak,
+                    "unit": "G wave-instructions/s", "frac": ach / peak}
     except Exception:  # noqa: BLE001
         pass
     return None

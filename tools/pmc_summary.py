@@ -50,6 +50,8 @@ if ck and anchors:
         with open(os.path.join(d, "traffic.json"), "w") as fh:
             json.dump({"kernel": ck, "anchors_per_launch": anchors, "hbm_read_bytes": rd, "hbm_write_bytes": wr,
                        "hbm_bytes_per_launch": rd + wr,
+                       "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
+                       "lds_insts_per_launch": c.get("SQ_INSTS_LDS"),
                        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KiB -> bytes, "
                                  "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B), average over launches"}, fh)
     if "GRBM_GUI_ACTIVE" in c:
