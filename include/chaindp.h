@@ -138,6 +138,15 @@ int chaindp_collect_seeds(chaindp_ctx_t *ctx, const chaindp_index_t *idx, int fl
                           const int64_t *mini_off, const chaindp_anchor_t *mini, const uint32_t *bid, const int32_t *qlen,
                           const int32_t *n_segs_per_read, int64_t *off, int32_t *rep_len, int64_t *mini_pos_off);
 int chaindp_download_mini_pos(chaindp_ctx_t *ctx, uint64_t *mini_pos);      /* mini_pos_off[n_reads] entries */
+/* The same with per-read buffers in PINNED host memory, moved by one kernel per direction (no staging copies):
+ * read_mini[r] = read r's minimizers (mini_off gives the counts); dst[r] receives read r's mini_pos[] zero-padded
+ * to 64 bytes (the reference's result packet layout, map.c:547-552), NULL skips the read.  The scatter is
+ * asynchronous: chaindp_sync() before reading dst. */
+int chaindp_collect_seeds_gather(chaindp_ctx_t *ctx, const chaindp_index_t *idx, int flag, int max_occ, int64_t n_reads,
+                                 const int64_t *mini_off, const chaindp_anchor_t *const *read_mini, const uint32_t *bid,
+                                 const int32_t *qlen, const int32_t *n_segs_per_read, int64_t *off, int32_t *rep_len,
+                                 int64_t *mini_pos_off);
+int chaindp_scatter_mini_pos(chaindp_ctx_t *ctx, int64_t n_reads, uint64_t *const *dst);
 int chaindp_download_anchors(chaindp_ctx_t *ctx, chaindp_anchor_t *a);      /* the resident batch's anchors */
 
 /* Pinned host memory (hipHostMalloc) for callers that want DMA-able staging buffers. */

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "chaindp_upload_gather", "chaindp_compact_offsets", "chaindp_download_seeds", "chaindp_host_alloc",
     "chaindp_host_free", "chaindp_run_device", "chaindp_set_profiling", "chaindp_get_kernel_ms",
     "chaindp_get_stats", "chaindp_set_ring", "chaindp_run_full", "chaindp_set_variant", "chaindp_upload_gather_ex", "chaindp_scatter_seeds", "chaindp_backtrack",
-    "chaindp_index_create", "chaindp_index_destroy", "chaindp_collect_seeds", "chaindp_download_mini_pos", "chaindp_download_anchors",
+    "chaindp_index_create", "chaindp_index_destroy", "chaindp_collect_seeds", "chaindp_download_mini_pos", "chaindp_download_anchors", "chaindp_collect_seeds_gather", "chaindp_scatter_mini_pos",
 )
 
 

@@ -681,22 +681,28 @@ static int seed_reserve(chaindp_ctx *ctx, int64_t n_mini)
 	return CHAINDP_OK;
 }
 
-extern "C" int chaindp_collect_seeds(chaindp_ctx_t *ctx, const chaindp_index_t *ix, int flag, int max_occ, int64_t n_reads,
-                                     const int64_t *mini_off, const chaindp_anchor_t *mini, const uint32_t *bid, const int32_t *qlen,
-                                     const int32_t *n_segs_per_read, int64_t *off, int32_t *rep_len, int64_t *mini_pos_off)
+// mini: all minimizers contiguous (read_mini == NULL), or read_mini[r] = read r's minimizers in pinned host memory
+static int collect_seeds_impl(chaindp_ctx *ctx, const chaindp_index_t *ix, int flag, int max_occ, int64_t n_reads,
+                              const int64_t *mini_off, const chaindp_anchor_t *mini, const chaindp_anchor_t *const *read_mini,
+                              const uint32_t *bid, const int32_t *qlen,
+                              const int32_t *n_segs_per_read, int64_t *off, int32_t *rep_len, int64_t *mini_pos_off)
 {
 	if (!ctx) return CHAINDP_ERR_ARG;
 	if (!ix || ix->device != ctx->device) { ctx->err = "index image missing or on another device"; return CHAINDP_ERR_ARG; }
 	if (n_reads < 0 || !mini_off || (n_reads > 0 && (mini_off[0] != 0 || !bid || !qlen))) { ctx->err = "bad minimizer offsets"; return CHAINDP_ERR_ARG; }
 	const int64_t n_mini = n_reads > 0 ? mini_off[n_reads] : 0;
-	if (n_mini < 0 || (n_mini > 0 && !mini)) { ctx->err = "bad minimizers"; return CHAINDP_ERR_ARG; }
+	if (n_mini < 0 || (n_mini > 0 && !mini && !read_mini)) { ctx->err = "bad minimizers"; return CHAINDP_ERR_ARG; }
 	if (n_reads > ctx->cap_reads) { ctx->err = "batch exceeds the capacity the context was created with"; return CHAINDP_ERR_CAPACITY; }
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int rc = seed_reserve(ctx, n_mini);
 	if (rc) return rc;
 	hipStream_t st = ctx->stream;
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mini_off, mini_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
-	if (n_mini) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mini, mini, (size_t)n_mini * 16, hipMemcpyHostToDevice, st));
+	if (n_mini && read_mini) {                                     // one kernel pulls every read's minimizers out of its pinned buffer
+		rc = stage_pointers(ctx, (const void *const *)read_mini, n_reads);
+		if (rc) return rc;
+		HIP_TRY(ctx, chaindp::launch_gather_reads(st, n_reads, ctx->d_mini_off, (const void *const *)ctx->d_ptrs, ctx->d_mini));
+	} else if (n_mini) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mini, mini, (size_t)n_mini * 16, hipMemcpyHostToDevice, st));
 	if (n_reads) {
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bid, bid, (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_qlen, qlen, (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
@@ -734,6 +740,33 @@ extern "C" int chaindp_collect_seeds(chaindp_ctx_t *ctx, const chaindp_index_t *
 	if (rep_len && n_reads) HIP_TRY(ctx, hipMemcpyAsync(rep_len, ctx->d_rep_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(ctx, hipStreamSynchronize(st));
 	ctx->n_reads = n_reads; ctx->total = (int64_t)totals[0]; ctx->n_mini_pos = (int64_t)totals[1]; ctx->ran = false;
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_collect_seeds(chaindp_ctx_t *ctx, const chaindp_index_t *ix, int flag, int max_occ, int64_t n_reads,
+                                     const int64_t *mini_off, const chaindp_anchor_t *mini, const uint32_t *bid, const int32_t *qlen,
+                                     const int32_t *n_segs_per_read, int64_t *off, int32_t *rep_len, int64_t *mini_pos_off)
+{
+	return collect_seeds_impl(ctx, ix, flag, max_occ, n_reads, mini_off, mini, nullptr, bid, qlen, n_segs_per_read, off, rep_len, mini_pos_off);
+}
+
+extern "C" int chaindp_collect_seeds_gather(chaindp_ctx_t *ctx, const chaindp_index_t *ix, int flag, int max_occ, int64_t n_reads,
+                                            const int64_t *mini_off, const chaindp_anchor_t *const *read_mini, const uint32_t *bid,
+                                            const int32_t *qlen, const int32_t *n_segs_per_read, int64_t *off, int32_t *rep_len,
+                                            int64_t *mini_pos_off)
+{
+	if (ctx && n_reads > 0 && !read_mini) { ctx->err = "bad minimizers"; return CHAINDP_ERR_ARG; }
+	return collect_seeds_impl(ctx, ix, flag, max_occ, n_reads, mini_off, nullptr, read_mini, bid, qlen, n_segs_per_read, off, rep_len, mini_pos_off);
+}
+
+extern "C" int chaindp_scatter_mini_pos(chaindp_ctx_t *ctx, int64_t n_reads, uint64_t *const *dst)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	if (n_reads != ctx->n_reads || (n_reads > 0 && !dst) || !ctx->d_mp_off) { ctx->err = "scatter does not match the last seed collection"; return CHAINDP_ERR_ARG; }
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc = stage_pointers(ctx, (const void *const *)dst, n_reads);
+	if (rc) return rc;
+	HIP_TRY(ctx, chaindp::launch_scatter_words(ctx->stream, n_reads, ctx->d_mp_off, (void *const *)ctx->d_ptrs, ctx->d_mini_pos));
 	return CHAINDP_OK;
 }
 

@@ -35,6 +35,29 @@ __global__ __launch_bounds__(256) void k_scatter_seeds(int64_t n_reads, const in
 	}
 }
 
+// dst[r][0 .. n_r) <- words[woff[r] .. woff[r+1]) (8-byte words, e.g. mini_pos[]); then zero up to the next 64-byte boundary
+__global__ __launch_bounds__(256) void k_scatter_words(int64_t n_reads, const int64_t *__restrict__ woff,
+                                                       unsigned long long *const *__restrict__ dst,
+                                                       const unsigned long long *__restrict__ words)
+{
+	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+		unsigned long long *d = dst[r];
+		if (!d) continue;
+		const int64_t w0 = woff[r], nw = woff[r + 1] - w0;
+		const int64_t nw_pad = ((nw * 8 + 63) & ~(int64_t)63) >> 3;
+		for (int64_t k = threadIdx.x; k < nw_pad; k += blockDim.x) d[k] = k < nw ? words[w0 + k] : 0ull;
+	}
+}
+
+hipError_t launch_scatter_words(hipStream_t st, int64_t n_reads, const int64_t *d_woff, void *const *d_dst, const void *d_words)
+{
+	if (n_reads <= 0) return hipSuccess;
+	const int64_t blocks = n_reads < 65535 ? n_reads : 65535;
+	hipLaunchKernelGGL(k_scatter_words, dim3((unsigned)blocks), dim3(256), 0, st, n_reads, d_woff,
+	                   (unsigned long long *const *)d_dst, (const unsigned long long*)d_words);
+	return hipGetLastError();
+}
+
 hipError_t launch_gather_reads(hipStream_t st, int64_t n_reads, const int64_t *d_off, const void *const *d_src, void *d_a)
 {
 	if (n_reads <= 0) return hipSuccess;

@@ -110,6 +110,7 @@ size_t seed_sort_lds_bytes(int max_n, int workers);
 // zero-copy movement between device-visible (pinned) host buffers and HBM: chaindp_io.hip
 hipError_t launch_gather_reads(hipStream_t st, int64_t n_reads, const int64_t *d_off, const void *const *d_src, void *d_a);
 hipError_t launch_scatter_seeds(hipStream_t st, int64_t n_reads, const int64_t *d_seeds_off, void *const *d_dst, const void *d_seeds);
+hipError_t launch_scatter_words(hipStream_t st, int64_t n_reads, const int64_t *d_woff, void *const *d_dst, const void *d_words);
 
 } // namespace chaindp
 #endif

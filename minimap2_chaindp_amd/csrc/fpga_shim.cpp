@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -105,7 +106,8 @@ struct ReadRef {
 	bool on_device;        // false: answered with err_flag = 1
 	int64_t batch_read;    // index in the device batch
 	int rep_len;           // minimizer packets: collect_result_t::rep_len / n_minipos and the mini_pos[] payload
-	std::vector<uint64_t> mini_pos;
+	int64_t n_minipos;
+	std::vector<uint64_t> mini_pos;    // only when the payload has to be staged on the host (several groups in one batch)
 };
 
 void fail_hard(const char *what)
@@ -161,7 +163,7 @@ void service_loop(int device)
 				const chaindp_pkt_task_t *t = (const chaindp_pkt_task_t*)q;
 				ReadRef rr;
 				rr.task = t; rr.anchors = (const chaindp_anchor_t*)(q + sizeof(chaindp_pkt_task_t));
-				rr.mini = nullptr; rr.n_anchors = t->seednum > 0 ? t->seednum : 0; rr.rep_len = 0;
+				rr.mini = nullptr; rr.n_anchors = t->seednum > 0 ? t->seednum : 0; rr.rep_len = 0; rr.n_minipos = 0;
 				rr.pkt = (int)k; rr.idx = i; rr.batch_read = -1;
 				rr.on_device = h->type == CHAINDP_PKT_ANCHORS && t->seednum >= 0 && t->gap_ref >= 0 && t->gap_qry >= 0;
 				if (h->type == CHAINDP_PKT_MINIMIZERS && have_index && t->seednum >= 0 && t->gap_ref >= 0 && t->gap_qry >= 0) {
@@ -185,6 +187,7 @@ void service_loop(int device)
 		std::vector<void*> group_stage;
 		std::vector<Result> out;
 		std::vector<chaindp_seed_t*> seed_dst(reads.size(), nullptr);         // where each read's records go in its result packet
+		std::vector<uint64_t*> minipos_dst(reads.size(), nullptr);            // ... and its mini_pos[]
 		int64_t n_reads_done = 0, n_anchors_done = 0, n_err = 0;
 
 		// lays out the result packets (map.c:494-567 writes them the same way; parsed at map.c:918-931):
@@ -198,7 +201,7 @@ void service_loop(int device)
 				for (int i = 0; i < (int)h->num; ++i) {
 					bytes += sizeof(chaindp_pkt_result_t);
 					if (reads[r0 + i].on_device) bytes += CHAINDP_ALIGN64((uint64_t)n_a[r0 + i] * sizeof(chaindp_seed_t))
-					                                       + CHAINDP_ALIGN64((uint64_t)reads[r0 + i].mini_pos.size() * sizeof(uint64_t));
+					                                       + CHAINDP_ALIGN64((uint64_t)reads[r0 + i].n_minipos * sizeof(uint64_t));
 				}
 				char *ob = (char*)g.pool.get(bytes);
 				if (!ob) fail_hard("out of pinned memory");
@@ -217,9 +220,9 @@ void service_loop(int device)
 						++n_err;
 					} else {
 						const uint64_t sb = (uint64_t)n_a[r0 + i] * sizeof(chaindp_seed_t), sp = CHAINDP_ALIGN64(sb);
-						const uint64_t mb = (uint64_t)rr.mini_pos.size() * sizeof(uint64_t), mp = CHAINDP_ALIGN64(mb);
+						const uint64_t mb = (uint64_t)rr.n_minipos * sizeof(uint64_t), mp = CHAINDP_ALIGN64(mb);
 						res->n_a = (uint32_t)n_a[r0 + i];
-						res->n_minipos = (uint32_t)rr.mini_pos.size(); res->rep_len = rr.rep_len;   // map.c:530-531; zero for anchor packets
+						res->n_minipos = (uint32_t)rr.n_minipos; res->rep_len = rr.rep_len;          // map.c:530-531; zero for anchor packets
 						res->sub_size = (uint32_t)(sizeof(chaindp_pkt_result_t) + sp + mp);
 						seed_dst[r0 + i] = (chaindp_seed_t*)q;
 						if (seed_src[r0 + i]) {
@@ -228,8 +231,8 @@ void service_loop(int device)
 						}
 						q += sp;
 						if (mp) {                                                             // mini_pos[] behind new_seed[] (map.c:547-552)
-							memcpy(q, rr.mini_pos.data(), mb);
-							if (mp > mb) memset(q + mb, 0, mp - mb);
+							minipos_dst[r0 + i] = (uint64_t*)q;                               // written by the device, or from the staged copy
+							if (!rr.mini_pos.empty()) { memcpy(q, rr.mini_pos.data(), mb); if (mp > mb) memset(q + mb, 0, mp - mb); }
 							q += mp;
 						}
 						n_anchors_done += rr.n_anchors;
@@ -258,27 +261,35 @@ void service_loop(int device)
 			}
 			std::vector<int64_t> soff(idx.size() + 1, 0);
 			int rc;
+			const bool trace = getenv("CHAINDP_SHIM_TRACE") != nullptr;
+			auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+			const double t_a = tnow();
+			double t_b = t_a, t_c = t_a;
 			if (from_minimizers) {
 				// the reference's device did the seed lookup (map.c:523 inside fpga_work): the read's minimizers go to the GPU,
 				// which looks them up in the index image, expands, sorts (chaindp_seed.hip) and leaves the anchors in HBM
 				std::vector<int64_t> moff(idx.size() + 1, 0), mpoff(idx.size() + 1, 0);
 				std::vector<uint32_t> bids(idx.size());
 				std::vector<int32_t> qlens(idx.size()), rlen(idx.size());
-				for (size_t k = 0; k < idx.size(); ++k) moff[k + 1] = moff[k] + reads[idx[k]].task->seednum;
-				std::vector<chaindp_anchor_t> mini((size_t)moff[idx.size()]);
+				std::vector<const chaindp_anchor_t*> mptr(idx.size());
 				for (size_t k = 0; k < idx.size(); ++k) {
 					const ReadRef &rr = reads[idx[k]];
-					if (rr.task->seednum) memcpy(mini.data() + moff[k], rr.mini, (size_t)rr.task->seednum * sizeof(chaindp_anchor_t));
-					bids[k] = rr.task->bid; qlens[k] = rr.task->qlensum;
+					moff[k + 1] = moff[k] + rr.task->seednum;
+					mptr[k] = rr.mini; bids[k] = rr.task->bid; qlens[k] = rr.task->qlensum;
 				}
-				rc = chaindp_collect_seeds(ctx, dev_index, sflag, max_occ, (int64_t)idx.size(), moff.data(), mini.data(), bids.data(), qlens.data(),
-				                           nseg.data(), off.data(), rlen.data(), mpoff.data());
-				std::vector<uint64_t> mp((size_t)(rc == CHAINDP_OK ? mpoff[idx.size()] : 0) + 1);
-				if (rc == CHAINDP_OK) rc = chaindp_download_mini_pos(ctx, mp.data());
+				t_b = tnow();
+				rc = chaindp_collect_seeds_gather(ctx, dev_index, sflag, max_occ, (int64_t)idx.size(), moff.data(), mptr.data(), bids.data(), qlens.data(),
+				                                  nseg.data(), off.data(), rlen.data(), mpoff.data());
+				t_c = tnow();
 				if (rc == CHAINDP_OK) for (size_t k = 0; k < idx.size(); ++k) {
 					ReadRef &rr = reads[idx[k]];
-					rr.n_anchors = off[k + 1] - off[k]; rr.rep_len = rlen[k];
-					rr.mini_pos.assign(mp.begin() + mpoff[k], mp.begin() + mpoff[k + 1]);
+					rr.n_anchors = off[k + 1] - off[k]; rr.rep_len = rlen[k]; rr.n_minipos = mpoff[k + 1] - mpoff[k];
+				}
+				if (rc == CHAINDP_OK && !single_group) {                                  // several groups: packets are assembled from staged copies
+					std::vector<uint64_t> mp((size_t)mpoff[idx.size()] + 1);
+					rc = chaindp_download_mini_pos(ctx, mp.data());
+					if (rc == CHAINDP_OK) for (size_t k = 0; k < idx.size(); ++k)
+						reads[idx[k]].mini_pos.assign(mp.begin() + mpoff[k], mp.begin() + mpoff[k + 1]);
 				}
 			} else {
 				// the packets are pinned driver buffers: one gather kernel pulls every read's anchors over PCIe
@@ -287,11 +298,13 @@ void service_loop(int device)
 			if (from_minimizers && rc == CHAINDP_ERR_CAPACITY) {
 				// more seeds than one device batch holds: hand these reads back the way the reference's device reports
 				// "cannot do it" (err_flag = 1, map.c:933-944) instead of failing the run
-				for (size_t k = 0; k < idx.size(); ++k) { reads[idx[k]].on_device = false; reads[idx[k]].mini_pos.clear(); }
+				for (size_t k = 0; k < idx.size(); ++k) { reads[idx[k]].on_device = false; reads[idx[k]].mini_pos.clear(); reads[idx[k]].n_minipos = 0; }
 				continue;
 			}
+			const double t_d = tnow();
 			if (rc == CHAINDP_OK) rc = chaindp_run(ctx, &par);
 			if (rc == CHAINDP_OK) rc = chaindp_compact_offsets(ctx, &par, soff.data());
+			const double t_e = tnow();
 			if (rc != CHAINDP_OK) { fprintf(stderr, "[chaindp-fpga] %s\n", chaindp_last_error(ctx)); fail_hard("device batch failed"); }
 			for (size_t k = 0; k < idx.size(); ++k) n_a[idx[k]] = soff[k + 1] - soff[k];
 			if (single_group) {
@@ -299,6 +312,11 @@ void service_loop(int device)
 				std::vector<chaindp_seed_t*> dst(idx.size());
 				for (size_t k = 0; k < idx.size(); ++k) dst[k] = seed_dst[idx[k]];
 				rc = chaindp_scatter_seeds(ctx, (int64_t)idx.size(), dst.data());      // device writes into the result packets
+				if (rc == CHAINDP_OK && from_minimizers) {
+					std::vector<uint64_t*> mdst(idx.size());
+					for (size_t k = 0; k < idx.size(); ++k) mdst[k] = minipos_dst[idx[k]];
+					rc = chaindp_scatter_mini_pos(ctx, (int64_t)idx.size(), mdst.data());
+				}
 				if (rc == CHAINDP_OK) rc = chaindp_sync(ctx);
 			} else {
 				const int64_t m = soff[idx.size()];
@@ -310,6 +328,8 @@ void service_loop(int device)
 				group_stage.push_back(stage);
 			}
 			if (rc != CHAINDP_OK) { fprintf(stderr, "[chaindp-fpga] %s\n", chaindp_last_error(ctx)); fail_hard("device batch failed"); }
+			if (trace) fprintf(stderr, "[chaindp-fpga] batch of %zu reads: gather %.2f ms, collect_seeds %.2f, mini_pos+bookkeeping %.2f, run+compact %.2f, packets+scatter %.2f\n",
+			                   idx.size(), t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, tnow() - t_e);
 			std::lock_guard<std::mutex> lk(g.mu);
 			g.stats[3] += 1;
 		}
