@@ -729,8 +729,8 @@ static int collect_seeds_impl(chaindp_ctx *ctx, const chaindp_index_t *ix, int f
 		int lds_limit = 0;
 		HIP_TRY(ctx, hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device));
 		int m = 8192, m2 = 65024;
-		while (m > 0 && chaindp::seed_sort_lds_bytes(m, 32) > (size_t)lds_limit) m -= 512;
-		while (m2 > m && chaindp::seed_sort_lds_bytes(m2, 4) > (size_t)lds_limit) m2 -= 512;
+		while (m > 0 && chaindp::seed_sort_lds_bytes(m, 32, 8) > (size_t)lds_limit) m -= 512;
+		while (m2 > m && chaindp::seed_sort_lds_bytes(m2, 4, 2) > (size_t)lds_limit) m2 -= 512;
 		ctx->seed_max_n = m; ctx->seed_max_n2 = m2;
 	}
 	HIP_TRY(ctx, chaindp::launch_seed_expand_sort(st, dix, flag, n_reads, n_mini, ctx->d_mini_off, ctx->d_mini, ctx->d_bid, ctx->d_qlen, ctx->seed,

@@ -103,9 +103,10 @@ hipError_t launch_seed_collect(hipStream_t st, const SeedIndex &ix, int flag, in
 hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag, int64_t n_reads, int64_t n_mini,
                                    const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, const int32_t *d_qlen, SeedScratch sc,
                                    void *d_unsorted, void *d_a, const int64_t *d_off, unsigned long long *d_mini_pos, int max_n, int max_n2);
-// LDS bytes of the per-read sort for reads of up to max_n anchors with `workers` bucket tables; the host picks the largest
-// max_n (<= 8192, 32 workers) and max_n2 (<= 65535, 4 workers) that fit the device's LDS per workgroup
-size_t seed_sort_lds_bytes(int max_n, int workers);
+// LDS bytes of the per-read sort for reads of up to max_n anchors with `workers` bucket tables and `coop` wave-wide
+// histograms; the host picks the largest max_n (<= 8192; 32 workers, 8 histograms) and max_n2 (4 workers, 2 histograms)
+// that fit the device's LDS per workgroup
+size_t seed_sort_lds_bytes(int max_n, int workers, int coop);
 
 // zero-copy movement between device-visible (pinned) host buffers and HBM: chaindp_io.hip
 hipError_t launch_gather_reads(hipStream_t st, int64_t n_reads, const int64_t *d_off, const void *const *d_src, void *d_a);

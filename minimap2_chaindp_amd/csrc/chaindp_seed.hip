@@ -16,6 +16,7 @@
 // Image layout: see csrc/seed_collect.h (the host-side statement of the same lookup, pinned on the CPU tier).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "chaindp_kernels.h"
 #include "chaindp_rsort.h"
 
@@ -240,7 +241,7 @@ __device__ __forceinline__ void seed_isort(uint64_t *key, uint16_t *idx, int beg
 }
 
 // takes the reads with min_n < anchors <= max_n; `workers` lanes (a power of two <= 64) have bucket tables
-__global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int min_n, int max_n, int workers, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int min_n, int max_n, int workers, int coop, int try_network, const int64_t *__restrict__ off,
                                                   const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ a)
 {
 	extern __shared__ uint64_t seed_lds[];
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int min_n, in
 	uint16_t *head = idx + max_n + (lane & (workers - 1)) * 512, *tail = head + 256;
 	SeedRange *qbase = (SeedRange*)(idx + max_n + workers * 512);
 	int *qn = (int*)(qbase + 2 * SEED_Q);                              // [parity][0 = big ranges, 1 = small ranges]
+	unsigned int *hist = (unsigned int*)(qn + 4);                      // coop x 256: digit counts of a round's first big ranges, made by all lanes
 	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
 		const int64_t b = off[r];
 		const int64_t n64 = off[r + 1] - b;
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int min_n, in
 		// reference's procedure below (whose serial top levels take milliseconds).
 		int pow2 = 64;
 		while (pow2 < n) pow2 <<= 1;
-		{
+		if (try_network) {
 			// bitonic network in its all-ascending form (first step of a merge compares mirror positions), so that the
 			// virtual +inf padding behind the n real keys never has to move and needs no storage
 			for (int i = lane; i < n; i += 64) { key[i] = src[b + i].x; idx[i] = (uint16_t)i; }
@@ -303,13 +305,26 @@ __global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int min_n, in
 			int *ncnt = qn + 2 * (which ^ 1);
 			const int n_big = qn[2 * which], n_small = min(qn[2 * which + 1], SEED_Q - SEED_QBIG);
 			if (n_big + n_small == 0) break;
+			// the top levels have one or two ranges of thousands of keys and a single lane each to permute them: at least
+			// their digit counts (ksort.h:126) are taken by the whole wave
+			const int n_coop = n_big < coop ? n_big : coop;
+			for (int w = 0; w < n_coop; ++w) {
+				const SeedRange rg = cur[w];
+				for (int d = lane; d < 256; d += 64) hist[w * 256 + d] = 0;
+				__syncthreads();
+				for (int q = rg.beg + lane; q < rg.end; q += 64) atomicAdd(&hist[w * 256 + (int)(key[q] >> rg.shift & 0xff)], 1u);
+			}
+			__syncthreads();
 			if (lane < workers) {
 				for (int w = lane; w < n_big + n_small; w += workers) {
 					const SeedRange rg = w < n_big ? cur[w] : cur[SEED_QBIG + (w - n_big)];
 					const int rb = rg.beg, re = rg.end, len = re - rb, sh = rg.shift;
 					if (len <= 64) { seed_isort(key, idx, rb, re); continue; }           // ksort.h:143,148
-					for (int d = 0; d < 256; ++d) tail[d] = 0;
-					for (int q = rb; q < re; ++q) ++tail[key[q] >> sh & 0xff];           // ksort.h:126
+					if (w < n_coop) for (int d = 0; d < 256; ++d) tail[d] = (uint16_t)hist[w * 256 + d];
+					else {
+						for (int d = 0; d < 256; ++d) tail[d] = 0;
+						for (int q = rb; q < re; ++q) ++tail[key[q] >> sh & 0xff];       // ksort.h:126
+					}
 					const int d0 = (int)(key[rb] >> sh & 0xff);
 					if (tail[d0] == len) {                                               // one bucket: the pass moves nothing
 						if (sh) nxt[atomicAdd(&ncnt[0], 1)] = SeedRange{(uint16_t)rb, (uint16_t)re, (uint16_t)(sh > 8 ? sh - 8 : 0), 0};
@@ -360,9 +375,9 @@ __global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int min_n, in
 	}
 }
 
-size_t seed_sort_lds_bytes(int max_n, int workers)
+size_t seed_sort_lds_bytes(int max_n, int workers, int coop)
 {
-	return (((size_t)max_n * 10 + 7) & ~(size_t)7) + (size_t)workers * 512 * 2 + 2 * (size_t)SEED_Q * sizeof(SeedRange) + 16;
+	return (((size_t)max_n * 10 + 7) & ~(size_t)7) + (size_t)workers * 512 * 2 + 2 * (size_t)SEED_Q * sizeof(SeedRange) + 16 + (size_t)coop * 1024;
 }
 
 hipError_t launch_seed_collect(hipStream_t st, const SeedIndex &ix, int flag, int max_occ, int64_t n_reads, int64_t n_mini,
@@ -393,8 +408,9 @@ hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag
 		// the LDS sort takes reads of up to max_n anchors (what fits the device's LDS per workgroup); anything larger goes
 		// to the one-thread version
 		const unsigned grid = (unsigned)(n_reads < 256 * 8 ? n_reads : 256 * 8);
-		if (max_n > 0) hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(64), seed_sort_lds_bytes(max_n, 32), st, n_reads, 0, max_n, 32, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a);
-		if (max_n2 > max_n) hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(64), seed_sort_lds_bytes(max_n2, 4), st, n_reads, max_n, max_n2, 4, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a);
+		const int try_network = getenv("CHAINDP_SEED_FORCE_EXACT") == nullptr;      // measurement switch: every read through the reference's procedure
+		if (max_n > 0) hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(64), seed_sort_lds_bytes(max_n, 32, 8), st, n_reads, 0, max_n, 32, 8, try_network, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a);
+		if (max_n2 > max_n) hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(64), seed_sort_lds_bytes(max_n2, 4, 2), st, n_reads, max_n, max_n2, 4, 2, try_network, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a);
 		hipLaunchKernelGGL(k_seed_sort_big, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, st, n_reads, max_n2 > max_n ? max_n2 : max_n, d_off, (const ulonglong2*)d_unsorted,
 		                   (ulonglong2*)d_a, (BtRange*)sc.stacks);
 	}
