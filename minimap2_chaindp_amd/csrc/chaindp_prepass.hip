@@ -27,6 +27,7 @@ namespace chaindp {
 // largest r in [lo, hi] with off[r] <= g   (off is non-decreasing; empty reads are skipped over)
 __device__ __forceinline__ int64_t read_of(const int64_t *__restrict__ off, int64_t lo, int64_t hi, int64_t g)
 {
+	if (hi - lo == 1) return g >= off[hi] ? hi : lo;               // a block that straddles one read boundary: the usual case
 	while (lo < hi) {
 		const int64_t mid = (lo + hi + 1) >> 1;
 		if (off[mid] <= g) lo = mid; else hi = mid - 1;
