@@ -41,13 +41,33 @@ __device__ __forceinline__ int64_t bt_read_of(const int64_t *__restrict__ off, i
 	return lo;
 }
 
+// B0: reads of the first and last record of every 1024-record block, so that the record-parallel kernels resolve
+// "which read is record g in" with one compare instead of a 14-step binary search per thread
+__global__ __launch_bounds__(256) void k_bt_block_reads(int64_t n_reads, int64_t m, const int64_t *__restrict__ soff, int2 *__restrict__ blk)
+{
+	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t g0 = b * BT_PER_BLOCK;
+	if (g0 >= m) return;
+	const int64_t g1 = g0 + BT_PER_BLOCK < m ? g0 + BT_PER_BLOCK : m;
+	const int64_t rlo = bt_read_of(soff, 0, n_reads - 1, g0);
+	blk[b] = make_int2((int)rlo, (int)bt_read_of(soff, rlo, n_reads - 1, g1 - 1));
+}
+
+__device__ __forceinline__ int64_t bt_read_of_blk(const int64_t *__restrict__ soff, const int2 *__restrict__ blk, int64_t g)
+{
+	const int2 rr = blk[g / BT_PER_BLOCK];
+	if (rr.x == rr.y) return rr.x;
+	if (rr.y - rr.x == 1) return g >= soff[rr.y] ? rr.y : rr.x;
+	return bt_read_of(soff, rr.x, rr.y, g);
+}
+
 // B1: has[j] = 1 if some record of the same read points at j (chain.c:347-349)
 __global__ __launch_bounds__(BT_BLOCK) void k_bt_children(int64_t n_reads, int64_t m, const int64_t *__restrict__ soff,
-                                                          const SeedRec *__restrict__ s, uint8_t *__restrict__ has)
+                                                          const SeedRec *__restrict__ s, uint8_t *__restrict__ has, const int2 *__restrict__ blk)
 {
 	for (int64_t g = (int64_t)blockIdx.x * BT_BLOCK + threadIdx.x; g < m; g += (int64_t)gridDim.x * BT_BLOCK) {
 		const int32_t p = s[g].p;
-		if (p >= 0) has[soff[bt_read_of(soff, 0, n_reads - 1, g)] + (p >> 2)] = 1;
+		if (p >= 0) has[soff[bt_read_of_blk(soff, blk, g)] + (p >> 2)] = 1;
 	}
 }
 
@@ -73,7 +93,7 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_end_count(int64_t m, const Seed
 __global__ __launch_bounds__(BT_BLOCK) void k_bt_end_list(int64_t n_reads, int64_t m, const int64_t *__restrict__ soff,
                                                           const SeedRec *__restrict__ s, const uint8_t *__restrict__ has,
                                                           const unsigned long long *__restrict__ block_base,
-                                                          int32_t *__restrict__ end_rec, int64_t *__restrict__ ends_off)
+                                                          int32_t *__restrict__ end_rec, int64_t *__restrict__ ends_off, const int2 *__restrict__ blk)
 {
 	__shared__ unsigned int s_w[4];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -91,7 +111,7 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_end_list(int64_t n_reads, int64
 		for (int w = 0; w < 4; ++w) { const unsigned int t = s_w[w]; if (w < wave) woff += t; tot += t; }
 		const unsigned int pos = carry + woff + __builtin_popcountll(bm & below);
 		if (g < g1) {
-			const int64_t r = bt_read_of(soff, 0, n_reads - 1, g);
+			const int64_t r = bt_read_of_blk(soff, blk, g);
 			const int64_t so = soff[r];
 			if (is_end) end_rec[pos] = (int32_t)(g - so);
 			if (g == so) for (int64_t rr = r; rr >= 0 && soff[rr] == so; --rr) ends_off[rr] = (int64_t)pos;
@@ -112,11 +132,13 @@ __global__ void k_bt_close_offsets(int64_t n_reads, int64_t m, const int64_t *__
 // B4: walk every end to the peak of f (chain.c:362-370)
 __global__ __launch_bounds__(BT_BLOCK) void k_bt_peaks(int64_t n_reads, const int64_t *__restrict__ soff, const SeedRec *__restrict__ s,
                                                        const int64_t *__restrict__ ends_off, const int32_t *__restrict__ end_rec,
-                                                       unsigned long long *__restrict__ key)
+                                                       unsigned long long *__restrict__ key, int32_t *__restrict__ end_read)
 {
 	const int64_t n_e = ends_off[n_reads];
 	for (int64_t e = (int64_t)blockIdx.x * BT_BLOCK + threadIdx.x; e < n_e; e += (int64_t)gridDim.x * BT_BLOCK) {
-		const SeedRec *sr = s + soff[bt_read_of(ends_off, 0, n_reads - 1, e)];
+		const int64_t r = bt_read_of(ends_off, 0, n_reads - 1, e);
+		end_read[e] = (int32_t)r;                                   // the later per-chain kernels (same list positions) reuse it
+		const SeedRec *sr = s + soff[r];
 		const int32_t i = end_rec[e];
 		int32_t j = i;
 		while (j >= 0 && (sr[j].p & 2)) j = sr[j].p >> 2;
@@ -152,25 +174,27 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_rank(int64_t n_reads, const int
 	}
 }
 
-// Reads whose records fit the LDS (BT_LDS_RECS of them: p and owner, 8 B each) get B6+B7 from one workgroup
-// working in LDS (k_bt_read_lds); the global-memory kernels below only serve the longer reads.
+// Reads whose records fit the LDS (p and owner, 8 B per record) get B6+B7 from one workgroup working in LDS
+// (k_bt_read_lds, launched twice: reads of up to BT_LDS_RECS records at two workgroups per CU, reads of up to
+// BT_LDS_RECS_MAX at one); the global-memory kernels below only serve the still longer reads.
 #define BT_LDS_RECS 8192
+#define BT_LDS_RECS_MAX 20000
 
 // B6+B7 for one read per workgroup, in LDS: owner by LDS atomicMin walkers (one thread per chain), then length,
 // score and fate of every chain.  Scattered returning atomics in HBM are ~9 G/s chip-wide; in LDS they cost ~100 cycles.
-__global__ __launch_bounds__(BT_BLOCK) void k_bt_read_lds(int64_t n_reads, int min_cnt, int min_sc, const int64_t *__restrict__ soff,
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_read_lds(int64_t n_reads, int min_recs, int max_recs, int min_cnt, int min_sc, const int64_t *__restrict__ soff,
                                                           const SeedRec *__restrict__ s, const int64_t *__restrict__ ends_off,
                                                           const unsigned long long *__restrict__ skey,
                                                           int32_t *__restrict__ ccnt, unsigned long long *__restrict__ cu)
 {
 	extern __shared__ int32_t bt_lds[];
-	int32_t *s_p = bt_lds, *s_own = bt_lds + BT_LDS_RECS;
+	int32_t *s_p = bt_lds, *s_own = bt_lds + max_recs;
 	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
 		const int64_t so = soff[r];
 		const int32_t m = (int32_t)(soff[r + 1] - so);
 		const int64_t cb = ends_off[r];
 		const int32_t nc = (int32_t)(ends_off[r + 1] - cb);
-		if (m <= 0 || m > BT_LDS_RECS || nc <= 0) continue;
+		if (m <= min_recs || m > max_recs || nc <= 0) continue;
 		const SeedRec *sr = s + so;
 		__syncthreads();
 		for (int32_t j = threadIdx.x; j < m; j += BT_BLOCK) { s_p[j] = sr[j].p; s_own[j] = 0x7fffffff; }
@@ -210,12 +234,12 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_read_lds(int64_t n_reads, int m
 // B6: owner[x] = best (smallest) rank among the chains whose path contains x
 __global__ __launch_bounds__(BT_BLOCK) void k_bt_own(int64_t n_reads, const int64_t *__restrict__ soff, const SeedRec *__restrict__ s,
                                                      const int64_t *__restrict__ ends_off, const unsigned long long *__restrict__ skey,
-                                                     int32_t *__restrict__ owner)
+                                                     int32_t *__restrict__ owner, const int32_t *__restrict__ end_read)
 {
 	const int64_t n_e = ends_off[n_reads];
 	for (int64_t c = (int64_t)blockIdx.x * BT_BLOCK + threadIdx.x; c < n_e; c += (int64_t)gridDim.x * BT_BLOCK) {
-		const int64_t r = bt_read_of(ends_off, 0, n_reads - 1, c);
-		if (soff[r + 1] - soff[r] <= BT_LDS_RECS) continue;         // done in LDS by k_bt_read_lds
+		const int64_t r = end_read[c];
+		if (soff[r + 1] - soff[r] <= BT_LDS_RECS_MAX) continue;     // done in LDS by k_bt_read_lds
 		const int32_t k = (int32_t)(c - ends_off[r]);
 		const SeedRec *sr = s + soff[r];
 		int32_t *ow = owner + soff[r];
@@ -232,12 +256,12 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_own(int64_t n_reads, const int6
 __global__ __launch_bounds__(BT_BLOCK) void k_bt_score(int64_t n_reads, int min_cnt, int min_sc, const int64_t *__restrict__ soff,
                                                        const SeedRec *__restrict__ s, const int64_t *__restrict__ ends_off,
                                                        const unsigned long long *__restrict__ skey, const int32_t *__restrict__ owner,
-                                                       int32_t *__restrict__ ccnt, unsigned long long *__restrict__ cu)
+                                                       int32_t *__restrict__ ccnt, unsigned long long *__restrict__ cu, const int32_t *__restrict__ end_read)
 {
 	const int64_t n_e = ends_off[n_reads];
 	for (int64_t c = (int64_t)blockIdx.x * BT_BLOCK + threadIdx.x; c < n_e; c += (int64_t)gridDim.x * BT_BLOCK) {
-		const int64_t r = bt_read_of(ends_off, 0, n_reads - 1, c);
-		if (soff[r + 1] - soff[r] <= BT_LDS_RECS) continue;         // done in LDS by k_bt_read_lds
+		const int64_t r = end_read[c];
+		if (soff[r + 1] - soff[r] <= BT_LDS_RECS_MAX) continue;     // done in LDS by k_bt_read_lds
 		const int32_t k = (int32_t)(c - ends_off[r]);
 		const SeedRec *sr = s + soff[r];
 		const int32_t *ow = owner + soff[r];
@@ -307,13 +331,13 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_emit(int64_t n_reads, const int
                                                       const int32_t *__restrict__ kpos, const int32_t *__restrict__ bpos,
                                                       const int64_t *__restrict__ chains_off, const int64_t *__restrict__ b_off,
                                                       ulonglong2 *__restrict__ b_tmp, unsigned long long *__restrict__ u_tmp,
-                                                      ulonglong2 *__restrict__ w)
+                                                      ulonglong2 *__restrict__ w, const int32_t *__restrict__ end_read)
 {
 	const int64_t n_e = ends_off[n_reads];
 	for (int64_t c = (int64_t)blockIdx.x * BT_BLOCK + threadIdx.x; c < n_e; c += (int64_t)gridDim.x * BT_BLOCK) {
 		const int32_t cnt = ccnt[c];
 		if (cnt <= 0) continue;
-		const int64_t r = bt_read_of(ends_off, 0, n_reads - 1, c);
+		const int64_t r = end_read[c];
 		const SeedRec *sr = s + soff[r];
 		ulonglong2 *dst = b_tmp + b_off[r] + bpos[c];
 		int32_t j = (int32_t)(uint32_t)skey[c];
@@ -393,23 +417,27 @@ hipError_t launch_backtrack(hipStream_t st, int min_cnt, int min_sc, int64_t n_r
 	const int64_t blocks = (m + BT_PER_BLOCK - 1) / BT_PER_BLOCK;
 	if ((e = hipMemsetAsync(sc.has, 0, (size_t)m, st)) != hipSuccess) return e;
 	if ((e = hipMemsetAsync(sc.owner, 0x7f, (size_t)m * 4, st)) != hipSuccess) return e;
-	hipLaunchKernelGGL(k_bt_children, dim3(bt_grid(m, BT_BLOCK)), dim3(BT_BLOCK), 0, st, n_reads, m, d_soff, s, sc.has);
+	int2 *blk = (int2*)sc.c_src;                                    // c_src is not needed before k_bt_xsort: 2 ints per 1024 records fit
+	hipLaunchKernelGGL(k_bt_block_reads, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, st, n_reads, m, d_soff, blk);
+	hipLaunchKernelGGL(k_bt_children, dim3(bt_grid(m, BT_BLOCK)), dim3(BT_BLOCK), 0, st, n_reads, m, d_soff, s, sc.has, blk);
 	hipLaunchKernelGGL(k_bt_end_count, dim3((unsigned)blocks), dim3(BT_BLOCK), 0, st, m, s, sc.has, sc.block_cnt);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, sc.total)) != hipSuccess) return e;
-	hipLaunchKernelGGL(k_bt_end_list, dim3((unsigned)blocks), dim3(BT_BLOCK), 0, st, n_reads, m, d_soff, s, sc.has, sc.block_cnt, sc.end_rec, sc.ends_off);
+	hipLaunchKernelGGL(k_bt_end_list, dim3((unsigned)blocks), dim3(BT_BLOCK), 0, st, n_reads, m, d_soff, s, sc.has, sc.block_cnt, sc.end_rec, sc.ends_off, blk);
 	hipLaunchKernelGGL(k_bt_close_offsets, dim3(1), dim3(1), 0, st, n_reads, m, d_soff, sc.total, sc.ends_off);
-	const unsigned gE = bt_grid(m, BT_BLOCK);                       // ends <= records
-	hipLaunchKernelGGL(k_bt_peaks, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, d_soff, s, sc.ends_off, sc.end_rec, sc.key);
+	const unsigned gE = bt_grid(m, BT_BLOCK) < 4096 ? bt_grid(m, BT_BLOCK) : 4096;   // per-chain kernels: ends <= records, usually far fewer; grid-stride loops
+	hipLaunchKernelGGL(k_bt_peaks, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, d_soff, s, sc.ends_off, sc.end_rec, sc.key, sc.c_dst);   // c_dst doubles as the end -> read table until k_bt_xsort
 	hipLaunchKernelGGL(k_bt_rank, dim3(bt_grid(n_reads, 1)), dim3(BT_BLOCK), 0, st, n_reads, sc.ends_off, sc.key, sc.skey);
-	hipLaunchKernelGGL(k_bt_read_lds, dim3(bt_grid(n_reads, 1)), dim3(BT_BLOCK), (size_t)BT_LDS_RECS * 8, st, n_reads, min_cnt, min_sc, d_soff, s,
+	hipLaunchKernelGGL(k_bt_read_lds, dim3(bt_grid(n_reads, 1)), dim3(BT_BLOCK), (size_t)BT_LDS_RECS * 8, st, n_reads, 0, BT_LDS_RECS, min_cnt, min_sc, d_soff, s,
 	                   sc.ends_off, sc.skey, sc.ccnt, sc.cu);
-	hipLaunchKernelGGL(k_bt_own, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, d_soff, s, sc.ends_off, sc.skey, sc.owner);
-	hipLaunchKernelGGL(k_bt_score, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, min_cnt, min_sc, d_soff, s, sc.ends_off, sc.skey, sc.owner, sc.ccnt, sc.cu);
+	hipLaunchKernelGGL(k_bt_read_lds, dim3(bt_grid(n_reads, 1) < 512 ? bt_grid(n_reads, 1) : 512), dim3(BT_BLOCK), (size_t)BT_LDS_RECS_MAX * 8, st, n_reads, BT_LDS_RECS, BT_LDS_RECS_MAX, min_cnt, min_sc, d_soff, s,
+	                   sc.ends_off, sc.skey, sc.ccnt, sc.cu);
+	hipLaunchKernelGGL(k_bt_own, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, d_soff, s, sc.ends_off, sc.skey, sc.owner, sc.c_dst);
+	hipLaunchKernelGGL(k_bt_score, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, min_cnt, min_sc, d_soff, s, sc.ends_off, sc.skey, sc.owner, sc.ccnt, sc.cu, sc.c_dst);
 	hipLaunchKernelGGL(k_bt_layout, dim3(bt_grid(n_reads, 4)), dim3(BT_BLOCK), 0, st, n_reads, sc.ends_off, sc.ccnt, sc.kpos, sc.bpos, sc.read_tot);
 	if ((e = launch_scan_u64(st, n_reads, sc.read_tot, sc.tile_tmp, sc.total)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_bt_offsets, dim3(bt_grid(n_reads + 1, 256)), dim3(256), 0, st, n_reads, sc.read_tot, sc.total, sc.chains_off, sc.b_off);
 	hipLaunchKernelGGL(k_bt_emit, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, d_soff, s, sc.ends_off, sc.skey, sc.ccnt, sc.cu, sc.kpos, sc.bpos,
-	                   sc.chains_off, sc.b_off, (ulonglong2*)sc.b_tmp, sc.u_tmp, (ulonglong2*)sc.w);
+	                   sc.chains_off, sc.b_off, (ulonglong2*)sc.b_tmp, sc.u_tmp, (ulonglong2*)sc.w, sc.c_dst);
 	hipLaunchKernelGGL(k_bt_xsort, dim3(bt_grid(n_reads, 64)), dim3(64), 0, st, n_reads, sc.chains_off, (ulonglong2*)sc.w, sc.u_tmp, sc.u_out,
 	                   sc.c_src, sc.c_dst, (BtRange*)sc.stacks);
 	hipLaunchKernelGGL(k_bt_copy, dim3(bt_grid(m, 64)), dim3(BT_BLOCK), 0, st, n_reads, sc.chains_off, sc.b_off, sc.u_out, sc.c_src, sc.c_dst,

@@ -41,7 +41,7 @@ def test_golden_chains(dev, name):
 ])
 def test_chains_match_oracle(dev, gen, preset, n_reads, min_cnt, over):
     par = P.preset(preset, **over)
-    kw = dict(read_len=2500, n_hits=10) if gen == "dense" else (dict(skew_max=20000) if gen == "skew" else {})
+    kw = dict(read_len=2500, n_hits=10) if gen == "dense" else (dict(skew_max=60000) if gen == "skew" else {})
     off, a = ag.generate(gen, n_reads=n_reads, seed=2024, **kw)
     f, p, v = dev.chain_batch(par, off, a)
     soff, seeds = dev.compact(par)
