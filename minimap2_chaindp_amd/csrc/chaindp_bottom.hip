@@ -357,7 +357,8 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_emit(int64_t n_reads, const int
 // B10: chains of a read in the reference's final order (chain.c:410-426); one thread per read
 __global__ __launch_bounds__(64) void k_bt_xsort(int64_t n_reads, const int64_t *__restrict__ chains_off, ulonglong2 *__restrict__ w,
                                                  const unsigned long long *__restrict__ u_tmp, unsigned long long *__restrict__ u_out,
-                                                 int32_t *__restrict__ c_src, int32_t *__restrict__ c_dst, BtRange *__restrict__ stacks)
+                                                 int32_t *__restrict__ c_src, int32_t *__restrict__ c_dst, BtRange *__restrict__ stacks,
+                                                 int32_t *__restrict__ chain_read)
 {
 	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (int64_t)gridDim.x * blockDim.x) {
 		const int64_t b = chains_off[r];
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(64) void k_bt_xsort(int64_t n_reads, const int64_t 
 			u_out[b + i] = u;
 			c_src[b + i] = (int32_t)(y >> 32);
 			c_dst[b + i] = k;
+			chain_read[b + i] = (int32_t)r;                         // for k_bt_copy, instead of a search per chain
 			k += (int32_t)(uint32_t)u;
 		}
 	}
@@ -380,14 +382,14 @@ __global__ __launch_bounds__(64) void k_bt_xsort(int64_t n_reads, const int64_t 
 __global__ __launch_bounds__(BT_BLOCK) void k_bt_copy(int64_t n_reads, const int64_t *__restrict__ chains_off, const int64_t *__restrict__ b_off,
                                                       const unsigned long long *__restrict__ u_out, const int32_t *__restrict__ c_src,
                                                       const int32_t *__restrict__ c_dst, const ulonglong2 *__restrict__ b_tmp,
-                                                      ulonglong2 *__restrict__ b_out)
+                                                      ulonglong2 *__restrict__ b_out, const int32_t *__restrict__ chain_read)
 {
 	const int lane = threadIdx.x & 63;
 	const int64_t n_c = chains_off[n_reads];
 	const int64_t wave0 = (int64_t)blockIdx.x * (BT_BLOCK >> 6) + (threadIdx.x >> 6);
 	const int64_t n_waves = (int64_t)gridDim.x * (BT_BLOCK >> 6);
 	for (int64_t c = wave0; c < n_c; c += n_waves) {
-		const int64_t bb = b_off[bt_read_of(chains_off, 0, n_reads - 1, c)];
+		const int64_t bb = b_off[chain_read[c]];
 		const int32_t n = (int32_t)(uint32_t)u_out[c];
 		const ulonglong2 *src = b_tmp + bb + c_src[c];
 		ulonglong2 *dst = b_out + bb + c_dst[c];
@@ -439,9 +441,9 @@ hipError_t launch_backtrack(hipStream_t st, int min_cnt, int min_sc, int64_t n_r
 	hipLaunchKernelGGL(k_bt_emit, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, d_soff, s, sc.ends_off, sc.skey, sc.ccnt, sc.cu, sc.kpos, sc.bpos,
 	                   sc.chains_off, sc.b_off, (ulonglong2*)sc.b_tmp, sc.u_tmp, (ulonglong2*)sc.w, sc.c_dst);
 	hipLaunchKernelGGL(k_bt_xsort, dim3(bt_grid(n_reads, 64)), dim3(64), 0, st, n_reads, sc.chains_off, (ulonglong2*)sc.w, sc.u_tmp, sc.u_out,
-	                   sc.c_src, sc.c_dst, (BtRange*)sc.stacks);
+	                   sc.c_src, sc.c_dst, (BtRange*)sc.stacks, sc.kpos);       // kpos is free after k_bt_emit: chain -> read
 	hipLaunchKernelGGL(k_bt_copy, dim3(bt_grid(m, 64)), dim3(BT_BLOCK), 0, st, n_reads, sc.chains_off, sc.b_off, sc.u_out, sc.c_src, sc.c_dst,
-	                   (const ulonglong2*)sc.b_tmp, (ulonglong2*)sc.b_out);
+	                   (const ulonglong2*)sc.b_tmp, (ulonglong2*)sc.b_out, sc.kpos);
 	return hipGetLastError();
 }
 
