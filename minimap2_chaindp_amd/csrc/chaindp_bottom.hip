@@ -63,16 +63,18 @@ __device__ __forceinline__ int64_t bt_read_of_blk(const int64_t *__restrict__ so
 
 // B1: has[j] = 1 if some record of the same read points at j (chain.c:347-349)
 __global__ __launch_bounds__(BT_BLOCK) void k_bt_children(int64_t n_reads, int64_t m, const int64_t *__restrict__ soff,
-                                                          const SeedRec *__restrict__ s, uint8_t *__restrict__ has, const int2 *__restrict__ blk)
+                                                          const SeedRec *__restrict__ s, uint8_t *__restrict__ has, const int2 *__restrict__ blk,
+                                                          int32_t *__restrict__ pdense)
 {
 	for (int64_t g = (int64_t)blockIdx.x * BT_BLOCK + threadIdx.x; g < m; g += (int64_t)gridDim.x * BT_BLOCK) {
 		const int32_t p = s[g].p;
+		pdense[g] = p;                                              // the later passes read 4 bytes per record instead of a 24-byte stride
 		if (p >= 0) has[soff[bt_read_of_blk(soff, blk, g)] + (p >> 2)] = 1;
 	}
 }
 
 // B2: chain ends per 1024-record block (chain.c:350-354)
-__global__ __launch_bounds__(BT_BLOCK) void k_bt_end_count(int64_t m, const SeedRec *__restrict__ s, const uint8_t *__restrict__ has,
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_end_count(int64_t m, const int32_t *__restrict__ pdense, const uint8_t *__restrict__ has,
                                                            unsigned long long *__restrict__ block_cnt)
 {
 	__shared__ unsigned int s_cnt;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_end_count(int64_t m, const Seed
 	const int64_t g0 = (int64_t)blockIdx.x * BT_PER_BLOCK;
 	const int64_t g1 = g0 + BT_PER_BLOCK < m ? g0 + BT_PER_BLOCK : m;
 	unsigned int mine = 0;
-	for (int64_t g = g0 + threadIdx.x; g < g1; g += BT_BLOCK) mine += (unsigned int)((s[g].p & 1) && !has[g]);
+	for (int64_t g = g0 + threadIdx.x; g < g1; g += BT_BLOCK) mine += (unsigned int)((pdense[g] & 1) && !has[g]);
 	for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d, 64);
 	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
 	__syncthreads();
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_end_count(int64_t m, const Seed
 // B3: the ends, in record order, as a flat list with per-read offsets (ends_off[r] = list position at the read's
 // first record; reads without records share their successor's value, the tail is closed by k_bt_close_offsets)
 __global__ __launch_bounds__(BT_BLOCK) void k_bt_end_list(int64_t n_reads, int64_t m, const int64_t *__restrict__ soff,
-                                                          const SeedRec *__restrict__ s, const uint8_t *__restrict__ has,
+                                                          const int32_t *__restrict__ pdense, const uint8_t *__restrict__ has,
                                                           const unsigned long long *__restrict__ block_base,
                                                           int32_t *__restrict__ end_rec, int64_t *__restrict__ ends_off, const int2 *__restrict__ blk)
 {
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_end_list(int64_t n_reads, int64
 	unsigned int carry = (unsigned int)block_base[blockIdx.x];
 	for (int64_t gb = g0; gb < g1; gb += BT_BLOCK) {
 		const int64_t g = gb + threadIdx.x;
-		const bool is_end = g < g1 && (s[g].p & 1) && !has[g];
+		const bool is_end = g < g1 && (pdense[g] & 1) && !has[g];
 		const uint64_t bm = __builtin_amdgcn_ballot_w64(is_end);
 		const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
 		if (lane == 0) s_w[wave] = __builtin_popcountll(bm);
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_rank(int64_t n_reads, const int
 __global__ __launch_bounds__(BT_BLOCK) void k_bt_read_lds(int64_t n_reads, int min_recs, int max_recs, int min_cnt, int min_sc, const int64_t *__restrict__ soff,
                                                           const SeedRec *__restrict__ s, const int64_t *__restrict__ ends_off,
                                                           const unsigned long long *__restrict__ skey,
-                                                          int32_t *__restrict__ ccnt, unsigned long long *__restrict__ cu)
+                                                          int32_t *__restrict__ ccnt, unsigned long long *__restrict__ cu, const int32_t *__restrict__ pdense)
 {
 	extern __shared__ int32_t bt_lds[];
 	int32_t *s_p = bt_lds, *s_own = bt_lds + max_recs;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_read_lds(int64_t n_reads, int m
 		if (m <= min_recs || m > max_recs || nc <= 0) continue;
 		const SeedRec *sr = s + so;
 		__syncthreads();
-		for (int32_t j = threadIdx.x; j < m; j += BT_BLOCK) { s_p[j] = sr[j].p; s_own[j] = 0x7fffffff; }
+		for (int32_t j = threadIdx.x; j < m; j += BT_BLOCK) { s_p[j] = pdense[so + j]; s_own[j] = 0x7fffffff; }
 		__syncthreads();
 		for (int32_t k = threadIdx.x; k < nc; k += BT_BLOCK) {          // walkers: rank k claims its path until a better rank owns it
 			int32_t j = (int32_t)(uint32_t)skey[cb + k];
@@ -420,19 +422,20 @@ hipError_t launch_backtrack(hipStream_t st, int min_cnt, int min_sc, int64_t n_r
 	if ((e = hipMemsetAsync(sc.has, 0, (size_t)m, st)) != hipSuccess) return e;
 	if ((e = hipMemsetAsync(sc.owner, 0x7f, (size_t)m * 4, st)) != hipSuccess) return e;
 	int2 *blk = (int2*)sc.c_src;                                    // c_src is not needed before k_bt_xsort: 2 ints per 1024 records fit
+	int32_t *pdense = (int32_t*)sc.u_out;                           // neither is u_out: the records' p fields, densely
 	hipLaunchKernelGGL(k_bt_block_reads, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, st, n_reads, m, d_soff, blk);
-	hipLaunchKernelGGL(k_bt_children, dim3(bt_grid(m, BT_BLOCK)), dim3(BT_BLOCK), 0, st, n_reads, m, d_soff, s, sc.has, blk);
-	hipLaunchKernelGGL(k_bt_end_count, dim3((unsigned)blocks), dim3(BT_BLOCK), 0, st, m, s, sc.has, sc.block_cnt);
+	hipLaunchKernelGGL(k_bt_children, dim3(bt_grid(m, BT_BLOCK)), dim3(BT_BLOCK), 0, st, n_reads, m, d_soff, s, sc.has, blk, pdense);
+	hipLaunchKernelGGL(k_bt_end_count, dim3((unsigned)blocks), dim3(BT_BLOCK), 0, st, m, pdense, sc.has, sc.block_cnt);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, sc.total)) != hipSuccess) return e;
-	hipLaunchKernelGGL(k_bt_end_list, dim3((unsigned)blocks), dim3(BT_BLOCK), 0, st, n_reads, m, d_soff, s, sc.has, sc.block_cnt, sc.end_rec, sc.ends_off, blk);
+	hipLaunchKernelGGL(k_bt_end_list, dim3((unsigned)blocks), dim3(BT_BLOCK), 0, st, n_reads, m, d_soff, pdense, sc.has, sc.block_cnt, sc.end_rec, sc.ends_off, blk);
 	hipLaunchKernelGGL(k_bt_close_offsets, dim3(1), dim3(1), 0, st, n_reads, m, d_soff, sc.total, sc.ends_off);
 	const unsigned gE = bt_grid(m, BT_BLOCK) < 4096 ? bt_grid(m, BT_BLOCK) : 4096;   // per-chain kernels: ends <= records, usually far fewer; grid-stride loops
 	hipLaunchKernelGGL(k_bt_peaks, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, d_soff, s, sc.ends_off, sc.end_rec, sc.key, sc.c_dst);   // c_dst doubles as the end -> read table until k_bt_xsort
 	hipLaunchKernelGGL(k_bt_rank, dim3(bt_grid(n_reads, 1)), dim3(BT_BLOCK), 0, st, n_reads, sc.ends_off, sc.key, sc.skey);
 	hipLaunchKernelGGL(k_bt_read_lds, dim3(bt_grid(n_reads, 1)), dim3(BT_BLOCK), (size_t)BT_LDS_RECS * 8, st, n_reads, 0, BT_LDS_RECS, min_cnt, min_sc, d_soff, s,
-	                   sc.ends_off, sc.skey, sc.ccnt, sc.cu);
+	                   sc.ends_off, sc.skey, sc.ccnt, sc.cu, pdense);
 	hipLaunchKernelGGL(k_bt_read_lds, dim3(bt_grid(n_reads, 1) < 512 ? bt_grid(n_reads, 1) : 512), dim3(BT_BLOCK), (size_t)BT_LDS_RECS_MAX * 8, st, n_reads, BT_LDS_RECS, BT_LDS_RECS_MAX, min_cnt, min_sc, d_soff, s,
-	                   sc.ends_off, sc.skey, sc.ccnt, sc.cu);
+	                   sc.ends_off, sc.skey, sc.ccnt, sc.cu, pdense);
 	hipLaunchKernelGGL(k_bt_own, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, d_soff, s, sc.ends_off, sc.skey, sc.owner, sc.c_dst);
 	hipLaunchKernelGGL(k_bt_score, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, min_cnt, min_sc, d_soff, s, sc.ends_off, sc.skey, sc.owner, sc.ccnt, sc.cu, sc.c_dst);
 	hipLaunchKernelGGL(k_bt_layout, dim3(bt_grid(n_reads, 4)), dim3(BT_BLOCK), 0, st, n_reads, sc.ends_off, sc.ccnt, sc.kpos, sc.bpos, sc.read_tot);
