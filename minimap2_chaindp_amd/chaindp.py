@@ -76,6 +76,11 @@ def lib():
         L.chaindp_index_destroy.argtypes = [vp]
         L.chaindp_collect_seeds.argtypes = [vp, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp]
         L.chaindp_download_mini_pos.argtypes = [vp, vp]
+        L.chaindp_collect_seeds_gather.argtypes = [vp, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.chaindp_scatter_mini_pos.argtypes = [vp, i64, vp]
+        L.chaindp_upload_gather_ex.argtypes = [vp, i64, vp, vp, vp, i32]
+        L.chaindp_scatter_seeds.argtypes = [vp, i64, vp]
+        L.chaindp_device_count.argtypes = []
         L.chaindp_download_anchors.argtypes = [vp, vp]
         _lib = L
     return _lib

@@ -28,6 +28,9 @@ def test_library_exports_every_declared_symbol():
         for n in names:
             assert hasattr(lib, n), f"{n} declared in include/{header} but not exported"
     assert set(chaindp.ABI_SYMBOLS) == set(_declared("chaindp.h"))
+    # every entry point is bound with explicit argument types (a default-int binding truncates 64-bit handles)
+    L = chaindp.lib()
+    assert [n for n in chaindp.ABI_SYMBOLS if getattr(L, n).argtypes is None] == []
     assert set(fpga.DRIVER_SYMBOLS) <= set(_declared("chaindp_fpga.h"))
 
 

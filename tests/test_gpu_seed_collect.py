@@ -166,3 +166,26 @@ def test_gpu_seed_collection_against_host_statement_on_synthetic_images(seed, ma
         assert rep_len[r] == exp[r][1] and np.array_equal(mp[mpo[r]:mpo[r + 1]], exp[r][2]), (seed, r)
     ties = sum(int((np.diff(e[0][:, 0]) == 0).sum()) for e in exp if len(e[0]) > 1)
     print(f"\nseed {seed}: anchors per read {sizes}, equal-x pairs {ties}")
+
+
+def test_seed_collection_argument_errors(dev):
+    g = np.load(SEEDS[0], allow_pickle=False)
+    L, ctx = dev._lib, dev._ctx
+    ix = dev.load_index([g["img_B"], g["img_H"], g["img_V"], g["img_P"]])
+    import ctypes as C
+    off = np.zeros(2, np.int64); rep = np.zeros(1, np.int32); mpo = np.zeros(2, np.int64)
+    mini_off = np.array([0, 3], np.int64); mini = np.zeros((3, 2), np.uint64); bid = np.zeros(1, np.uint32); qlen = np.full(1, 100, np.int32)
+    args = lambda **kw: [kw.get("ctx", ctx), kw.get("ix", ix), 0, 50, kw.get("n", 1), kw.get("mo", mini_off.ctypes.data), kw.get("mi", mini.ctypes.data),
+                         kw.get("bid", bid.ctypes.data), qlen.ctypes.data, None, off.ctypes.data, rep.ctypes.data, mpo.ctypes.data]
+    assert L.chaindp_collect_seeds(*args()) == 0
+    assert L.chaindp_collect_seeds(*args(ix=None)) != 0                       # no index image
+    assert L.chaindp_collect_seeds(*args(mo=None)) != 0                       # no offsets
+    assert L.chaindp_collect_seeds(*args(mi=None)) != 0                       # minimizers announced but absent
+    assert L.chaindp_collect_seeds(*args(bid=None)) != 0
+    assert L.chaindp_collect_seeds(*args(n=-1)) != 0
+    assert b"index" in L.chaindp_last_error(ctx) or len(L.chaindp_last_error(ctx)) > 0
+    # an image without its B blob is refused at creation
+    assert not L.chaindp_index_create(0, None, 0, g["img_H"].ctypes.data, g["img_H"].size, g["img_V"].ctypes.data, g["img_V"].size, None, 0)
+    # scatter without a matching seed collection
+    dst = (C.c_void_p * 4)()
+    assert L.chaindp_scatter_mini_pos(ctx, 4, dst) != 0
