@@ -102,3 +102,35 @@ def test_unmodified_minimizer_packets_end_to_end(path):
         assert seen[r][0].tobytes() == exp.tobytes(), (os.path.basename(path), r, "new_seed[]")
         assert np.array_equal(seen[r][1], g["mini_pos"][g["mp_off"][r]:g["mp_off"][r + 1]]), (r, "mini_pos")
         assert seen[r][2] == int(g["rep_len"][r]), (r, "rep_len")
+
+
+def test_minimizer_and_anchor_packets_in_one_stream():
+    """Both payload kinds submitted back to back (they share device batches, which then have several groups and assemble
+    their result packets from staged copies): every read comes back right whichever way its seeds travelled."""
+    path = [p for p in SEED_FIXTURES if "syn_repeats_mapont" in p][0]
+    g = np.load(path, allow_pickle=False)
+    pv = [int(x) for x in g["params"]]
+    par = P.ChainParams(max_dist_x=pv[0], max_dist_y=pv[1], bw=pv[2], max_skip=pv[3], min_sc=pv[4], is_cdna=pv[5], n_segs=1)
+    n = len(g["bid"])
+    anchors = [np.ascontiguousarray(g["anchors"][g["a_off"][r]:g["a_off"][r + 1]]) for r in range(n)]
+    with fpga.Driver(bw=par.bw, is_cdna=par.is_cdna, max_skip=par.max_skip, min_sc=par.min_sc, flag=int(g["flag"]),
+                     max_occ=int(g["mid_occ"]), index=[g["img_B"], g["img_H"], g["img_V"], g["img_P"]]) as drv:
+        pkts = []
+        for r in range(n):                               # read r as minimizers (id r) and as anchors (id 1000 + r), alternating
+            pkts.append(fpga.build_task_packet([(r, g["mini"][g["mini_off"][r]:g["mini_off"][r + 1]], int(g["bid"][r]), int(g["qlen"][r]))],
+                                               par.max_dist_x, par.max_dist_y, pkt_type=fpga.PKT_MINIMIZERS))
+            pkts.append(fpga.build_task_packet([(1000 + r, anchors[r])], par.max_dist_x, par.max_dist_y))
+        for k, pk in enumerate(pkts):
+            drv.submit(pk, tid=k % 4)
+        results = drv.wait_results(len(pkts))
+    seen = {}
+    for raw in results:
+        for read_id, err, seeds, mini_pos, rep_len in fpga.parse_result_packet_full(raw):
+            assert err == 0
+            seen[read_id] = (seeds, mini_pos, rep_len)
+    for r in range(n):
+        f, p, v, _ = ol.oracle_fpv(par, anchors[r])
+        exp = ol.oracle_compact(par, anchors[r], f, p, v)
+        assert seen[r][0].tobytes() == exp.tobytes() and seen[1000 + r][0].tobytes() == exp.tobytes(), r
+        assert np.array_equal(seen[r][1], g["mini_pos"][g["mp_off"][r]:g["mp_off"][r + 1]]) and seen[r][2] == int(g["rep_len"][r])
+        assert len(seen[1000 + r][1]) == 0 and seen[1000 + r][2] == 0
