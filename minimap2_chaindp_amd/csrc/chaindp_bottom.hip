@@ -326,7 +326,100 @@ __global__ void k_bt_offsets(int64_t n_reads, const unsigned long long *__restri
 	}
 }
 
+// B9-B11 for one read per workgroup, in LDS (reads of up to max_recs records; the three kernels below serve the longer
+// ones): every kept chain is walked in LDS (p staged densely) into a list of record indices in rank order, the read's
+// chains are put into the reference's final order (chain.c:410-426: radix_sort_128x on the first anchor's x, by one
+// thread -- a read has tens of chains), and the anchors are gathered straight into their final places.  Replaces a
+// pointer chase through HBM per chain, an intermediate copy of all chain anchors and a second pass over them.
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_emit_lds(int64_t n_reads, int min_recs, int max_recs, const int64_t *__restrict__ soff,
+                                                          const SeedRec *__restrict__ s, const int32_t *__restrict__ pdense,
+                                                          const int64_t *__restrict__ ends_off, const unsigned long long *__restrict__ skey,
+                                                          const int32_t *__restrict__ ccnt, const unsigned long long *__restrict__ cu,
+                                                          const int32_t *__restrict__ kpos, const int32_t *__restrict__ bpos,
+                                                          const int64_t *__restrict__ chains_off, const int64_t *__restrict__ b_off,
+                                                          unsigned long long *__restrict__ u_tmp, unsigned long long *__restrict__ u_out,
+                                                          ulonglong2 *__restrict__ w, BtRange *__restrict__ stacks,
+                                                          int32_t *__restrict__ chain_read, ulonglong2 *__restrict__ b_out)
+{
+	extern __shared__ int32_t bt_lds[];
+	int32_t *s_p = bt_lds, *s_list = bt_lds + max_recs;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+		const int64_t so = soff[r];
+		const int32_t m = (int32_t)(soff[r + 1] - so);
+		const int64_t cb = ends_off[r], kb = chains_off[r], bb = b_off[r];
+		const int32_t nc = (int32_t)(ends_off[r + 1] - cb), nk = (int32_t)(chains_off[r + 1] - kb);
+		if (m <= min_recs || m > max_recs || nk <= 0) continue;
+		const SeedRec *sr = s + so;
+		__syncthreads();
+		for (int32_t j = threadIdx.x; j < m; j += BT_BLOCK) s_p[j] = pdense[so + j];
+		__syncthreads();
+		for (int32_t k = threadIdx.x; k < nc; k += BT_BLOCK) {          // chain.c:404-406: reversed walk order, as record indices
+			const int32_t cnt = ccnt[cb + k];
+			if (cnt <= 0) continue;
+			const int32_t pos = bpos[cb + k], ck = kpos[cb + k];
+			int32_t j = (int32_t)(uint32_t)skey[cb + k];
+			for (int32_t t = cnt - 1; t >= 0; --t) {
+				s_list[pos + t] = j;
+				const int32_t p = s_p[j];
+				j = p >= 0 ? p >> 2 : -1;
+			}
+			u_tmp[kb + ck] = cu[cb + k];
+			w[kb + ck] = make_ulonglong2(sr[s_list[pos]].x, (unsigned long long)(uint32_t)pos << 32 | (unsigned long long)(uint32_t)ck);
+		}
+		__threadfence_block();
+		__syncthreads();
+		if (nk <= 64) {
+			// chain.c:410-426 for up to 64 chains is the reference's insertion sort, which is stable: the final place of a
+			// chain is the number of chains with a smaller first x, or an equal one and a smaller index -- by one wave
+			if (wave == 0) {
+				uint64_t *f_u = (uint64_t*)(bt_lds + 2 * max_recs);
+				int32_t *f_pos = (int32_t*)(f_u + 64);
+				const ulonglong2 me = lane < nk ? w[kb + lane] : make_ulonglong2(~0ull, 0);
+				int32_t rank = 0;
+				for (int j = 0; j < nk; ++j) {
+					const uint64_t xj = (uint64_t)__shfl((unsigned long long)me.x, j, 64);
+					rank += xj < me.x || (xj == me.x && j < lane);
+				}
+				if (lane < nk) { f_u[rank] = u_tmp[kb + (uint32_t)me.y]; f_pos[rank] = (int32_t)(me.y >> 32); }
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				const uint64_t u = lane < nk ? f_u[lane] : 0;
+				const uint32_t cnt = (uint32_t)u;
+				uint32_t incl = cnt;
+				for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+				if (lane < nk) {
+					u_out[kb + lane] = u;
+					chain_read[kb + lane] = (int32_t)r;
+					w[kb + lane] = make_ulonglong2((unsigned long long)(uint32_t)f_pos[lane], (unsigned long long)(incl - cnt) << 32 | cnt);
+				}
+			}
+		} else if (threadIdx.x == 0) {                                   // chain.c:410-426, more than 64 chains: the radix procedure
+			bt_radix_128x(w + kb, nk, stacks + kb / 64 + 2 * r);
+			int32_t k = 0;
+			for (int32_t i = 0; i < nk; ++i) {
+				const unsigned long long y = w[kb + i].y;
+				const unsigned long long u = u_tmp[kb + (uint32_t)y];
+				u_out[kb + i] = u;
+				chain_read[kb + i] = (int32_t)r;
+				w[kb + i] = make_ulonglong2(y >> 32, (unsigned long long)(uint32_t)k << 32 | (uint32_t)u);   // list position, final offset | count
+				k += (int32_t)(uint32_t)u;
+			}
+		}
+		__threadfence_block();
+		__syncthreads();
+		for (int32_t i = wave; i < nk; i += BT_BLOCK >> 6) {             // one wave per chain: gather into the final place
+			const ulonglong2 e = w[kb + i];
+			const int32_t src = (int32_t)e.x, dst = (int32_t)(e.y >> 32), n = (int32_t)(uint32_t)e.y;
+			for (int32_t t = lane; t < n; t += 64) {
+				const SeedRec rec = sr[s_list[src + t]];
+				b_out[bb + dst + t] = make_ulonglong2(rec.x, rec.y);
+			}
+		}
+	}
+}
+
 // B9: kept chains, still in rank order: anchors (ascending along the chain), u, and the sort keys of chain.c:412-416
+// (B9-B11 below: only for reads too long for k_bt_emit_lds)
 __global__ __launch_bounds__(BT_BLOCK) void k_bt_emit(int64_t n_reads, const int64_t *__restrict__ soff, const SeedRec *__restrict__ s,
                                                       const int64_t *__restrict__ ends_off, const unsigned long long *__restrict__ skey,
                                                       const int32_t *__restrict__ ccnt, const unsigned long long *__restrict__ cu,
@@ -340,6 +433,7 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_emit(int64_t n_reads, const int
 		const int32_t cnt = ccnt[c];
 		if (cnt <= 0) continue;
 		const int64_t r = end_read[c];
+		if (soff[r + 1] - soff[r] <= BT_LDS_RECS_MAX) continue;     // done by k_bt_emit_lds
 		const SeedRec *sr = s + soff[r];
 		ulonglong2 *dst = b_tmp + b_off[r] + bpos[c];
 		int32_t j = (int32_t)(uint32_t)skey[c];
@@ -357,7 +451,7 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_emit(int64_t n_reads, const int
 }
 
 // B10: chains of a read in the reference's final order (chain.c:410-426); one thread per read
-__global__ __launch_bounds__(64) void k_bt_xsort(int64_t n_reads, const int64_t *__restrict__ chains_off, ulonglong2 *__restrict__ w,
+__global__ __launch_bounds__(64) void k_bt_xsort(int64_t n_reads, const int64_t *__restrict__ soff, const int64_t *__restrict__ chains_off, ulonglong2 *__restrict__ w,
                                                  const unsigned long long *__restrict__ u_tmp, unsigned long long *__restrict__ u_out,
                                                  int32_t *__restrict__ c_src, int32_t *__restrict__ c_dst, BtRange *__restrict__ stacks,
                                                  int32_t *__restrict__ chain_read)
@@ -365,7 +459,7 @@ __global__ __launch_bounds__(64) void k_bt_xsort(int64_t n_reads, const int64_t 
 	for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (int64_t)gridDim.x * blockDim.x) {
 		const int64_t b = chains_off[r];
 		const int32_t n = (int32_t)(chains_off[r + 1] - b);
-		if (n <= 0) continue;
+		if (n <= 0 || soff[r + 1] - soff[r] <= BT_LDS_RECS_MAX) continue;   // short reads: k_bt_emit_lds
 		bt_radix_128x(w + b, n, stacks + b / 64 + 2 * r);           // at most n/65 pending ranges
 		int32_t k = 0;
 		for (int32_t i = 0; i < n; ++i) {
@@ -381,7 +475,7 @@ __global__ __launch_bounds__(64) void k_bt_xsort(int64_t n_reads, const int64_t 
 }
 
 // B11: anchors into their final place, one wave per chain
-__global__ __launch_bounds__(BT_BLOCK) void k_bt_copy(int64_t n_reads, const int64_t *__restrict__ chains_off, const int64_t *__restrict__ b_off,
+__global__ __launch_bounds__(BT_BLOCK) void k_bt_copy(int64_t n_reads, const int64_t *__restrict__ soff, const int64_t *__restrict__ chains_off, const int64_t *__restrict__ b_off,
                                                       const unsigned long long *__restrict__ u_out, const int32_t *__restrict__ c_src,
                                                       const int32_t *__restrict__ c_dst, const ulonglong2 *__restrict__ b_tmp,
                                                       ulonglong2 *__restrict__ b_out, const int32_t *__restrict__ chain_read)
@@ -391,7 +485,9 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_copy(int64_t n_reads, const int
 	const int64_t wave0 = (int64_t)blockIdx.x * (BT_BLOCK >> 6) + (threadIdx.x >> 6);
 	const int64_t n_waves = (int64_t)gridDim.x * (BT_BLOCK >> 6);
 	for (int64_t c = wave0; c < n_c; c += n_waves) {
-		const int64_t bb = b_off[chain_read[c]];
+		const int64_t r = chain_read[c];
+		if (soff[r + 1] - soff[r] <= BT_LDS_RECS_MAX) continue;     // short reads: k_bt_emit_lds
+		const int64_t bb = b_off[r];
 		const int32_t n = (int32_t)(uint32_t)u_out[c];
 		const ulonglong2 *src = b_tmp + bb + c_src[c];
 		ulonglong2 *dst = b_out + bb + c_dst[c];
@@ -422,7 +518,8 @@ hipError_t launch_backtrack(hipStream_t st, int min_cnt, int min_sc, int64_t n_r
 	if ((e = hipMemsetAsync(sc.has, 0, (size_t)m, st)) != hipSuccess) return e;
 	if ((e = hipMemsetAsync(sc.owner, 0x7f, (size_t)m * 4, st)) != hipSuccess) return e;
 	int2 *blk = (int2*)sc.c_src;                                    // c_src is not needed before k_bt_xsort: 2 ints per 1024 records fit
-	int32_t *pdense = (int32_t*)sc.u_out;                           // neither is u_out: the records' p fields, densely
+	int32_t *pdense = (int32_t*)sc.b_tmp;                           // b_tmp is only written by the long reads' k_bt_emit, at the very end: the records' p fields, densely
+	int32_t *chain_read = (int32_t*)sc.key;                         // key is dead after k_bt_rank: final chain -> read
 	hipLaunchKernelGGL(k_bt_block_reads, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, st, n_reads, m, d_soff, blk);
 	hipLaunchKernelGGL(k_bt_children, dim3(bt_grid(m, BT_BLOCK)), dim3(BT_BLOCK), 0, st, n_reads, m, d_soff, s, sc.has, blk, pdense);
 	hipLaunchKernelGGL(k_bt_end_count, dim3((unsigned)blocks), dim3(BT_BLOCK), 0, st, m, pdense, sc.has, sc.block_cnt);
@@ -441,12 +538,19 @@ hipError_t launch_backtrack(hipStream_t st, int min_cnt, int min_sc, int64_t n_r
 	hipLaunchKernelGGL(k_bt_layout, dim3(bt_grid(n_reads, 4)), dim3(BT_BLOCK), 0, st, n_reads, sc.ends_off, sc.ccnt, sc.kpos, sc.bpos, sc.read_tot);
 	if ((e = launch_scan_u64(st, n_reads, sc.read_tot, sc.tile_tmp, sc.total)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_bt_offsets, dim3(bt_grid(n_reads + 1, 256)), dim3(256), 0, st, n_reads, sc.read_tot, sc.total, sc.chains_off, sc.b_off);
+	hipLaunchKernelGGL(k_bt_emit_lds, dim3(bt_grid(n_reads, 1)), dim3(BT_BLOCK), (size_t)BT_LDS_RECS * 8 + 1024, st, n_reads, 0, BT_LDS_RECS, d_soff, s, pdense,
+	                   sc.ends_off, sc.skey, sc.ccnt, sc.cu, sc.kpos, sc.bpos, sc.chains_off, sc.b_off, sc.u_tmp, sc.u_out, (ulonglong2*)sc.w,
+	                   (BtRange*)sc.stacks, chain_read, (ulonglong2*)sc.b_out);
+	hipLaunchKernelGGL(k_bt_emit_lds, dim3(bt_grid(n_reads, 1) < 512 ? bt_grid(n_reads, 1) : 512), dim3(BT_BLOCK), (size_t)BT_LDS_RECS_MAX * 8 + 1024, st, n_reads,
+	                   BT_LDS_RECS, BT_LDS_RECS_MAX, d_soff, s, pdense, sc.ends_off, sc.skey, sc.ccnt, sc.cu, sc.kpos, sc.bpos, sc.chains_off, sc.b_off,
+	                   sc.u_tmp, sc.u_out, (ulonglong2*)sc.w, (BtRange*)sc.stacks, chain_read, (ulonglong2*)sc.b_out);
+	// reads with more than BT_LDS_RECS_MAX records: the same three steps through global memory
 	hipLaunchKernelGGL(k_bt_emit, dim3(gE), dim3(BT_BLOCK), 0, st, n_reads, d_soff, s, sc.ends_off, sc.skey, sc.ccnt, sc.cu, sc.kpos, sc.bpos,
 	                   sc.chains_off, sc.b_off, (ulonglong2*)sc.b_tmp, sc.u_tmp, (ulonglong2*)sc.w, sc.c_dst);
-	hipLaunchKernelGGL(k_bt_xsort, dim3(bt_grid(n_reads, 64)), dim3(64), 0, st, n_reads, sc.chains_off, (ulonglong2*)sc.w, sc.u_tmp, sc.u_out,
-	                   sc.c_src, sc.c_dst, (BtRange*)sc.stacks, sc.kpos);       // kpos is free after k_bt_emit: chain -> read
-	hipLaunchKernelGGL(k_bt_copy, dim3(bt_grid(m, 64)), dim3(BT_BLOCK), 0, st, n_reads, sc.chains_off, sc.b_off, sc.u_out, sc.c_src, sc.c_dst,
-	                   (const ulonglong2*)sc.b_tmp, (ulonglong2*)sc.b_out, sc.kpos);
+	hipLaunchKernelGGL(k_bt_xsort, dim3(bt_grid(n_reads, 64)), dim3(64), 0, st, n_reads, d_soff, sc.chains_off, (ulonglong2*)sc.w, sc.u_tmp, sc.u_out,
+	                   sc.c_src, sc.c_dst, (BtRange*)sc.stacks, chain_read);
+	hipLaunchKernelGGL(k_bt_copy, dim3(bt_grid(m, 64) < 8192 ? bt_grid(m, 64) : 8192), dim3(BT_BLOCK), 0, st, n_reads, d_soff, sc.chains_off, sc.b_off, sc.u_out, sc.c_src, sc.c_dst,
+	                   (const ulonglong2*)sc.b_tmp, (ulonglong2*)sc.b_out, chain_read);
 	return hipGetLastError();
 }
 
