@@ -36,6 +36,15 @@ def test_gpu_collect_seed_hits_matches_reference_and_feeds_the_dp(dev, path):
     if len(a):
         of, op, ov, _ = ol.oracle_batch(par, off, np.ascontiguousarray(g["anchors"]), threads=4)
         assert np.array_equal(f, of) and np.array_equal(p, op) and np.array_equal(v, ov)
+        # ... and on to new_seed[] and the chains of mm_chain_dp_bottom, all without leaving the device
+        soff, seeds = dev.compact(par)
+        coff, u, boff, b = dev.backtrack(par, pv[7])
+        for r in range(len(off) - 1):
+            ar = np.ascontiguousarray(g["anchors"][off[r]:off[r + 1]])
+            exp = ol.oracle_compact(par, ar, of[off[r]:off[r + 1]].copy(), op[off[r]:off[r + 1]].copy(), ov[off[r]:off[r + 1]].copy())
+            assert seeds[int(soff[r]):int(soff[r + 1])].tobytes() == exp.tobytes(), (r, "new_seed")
+            eu, eb = ol.oracle_bottom(pv[7], par.min_sc, exp)
+            assert np.array_equal(u[int(coff[r]):int(coff[r + 1])], eu) and np.array_equal(b[int(boff[r]):int(boff[r + 1])], eb.reshape(-1, 2)), (r, "chains")
 
 
 def test_gpu_seed_collection_edge_cases(dev):
