@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -58,6 +59,7 @@ struct chaindp_ctx {
 	unsigned long long *d_mini_pos = nullptr;
 	int64_t seed_cap_mini = 0, n_mini_pos = 0;
 	int seed_max_n = -1, seed_max_n2 = -1; // largest reads the two configurations of the LDS sort take on this device
+	int seed_lab_cap = 0;                  // digits k_seed_sort_huge keeps in LDS
 	// profiling
 	bool prof = false;
 	std::vector<EventSet> pending;
@@ -659,7 +661,7 @@ static int seed_reserve(chaindp_ctx *ctx, int64_t n_mini)
 		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bid, (nr + 1) * 4));
 		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qlen, (nr + 1) * 4));
 		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_rep_len, (nr + 1) * 4));
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->seed.totals, 16));
+		HIP_TRY(ctx, hipMalloc((void**)&ctx->seed.totals, 32));
 		HIP_TRY(ctx, hipMalloc((void**)&ctx->seed.stacks, ((size_t)ctx->cap_anchors / 64 + 2 * nr + 4) * 12));
 	}
 	if (n_mini > ctx->seed_cap_mini) {
@@ -728,13 +730,20 @@ static int collect_seeds_impl(chaindp_ctx *ctx, const chaindp_index_t *ix, int f
 	if (ctx->seed_max_n < 0) {
 		int lds_limit = 0;
 		HIP_TRY(ctx, hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device));
-		int m = 8192, m2 = 65024;
+		int m = 8192, m2 = 65024, cap = (lds_limit - 8192) & ~15;
+		// test switches: smaller limits send ordinary reads down the paths made for very large ones
+		if (const char *v = getenv("CHAINDP_SEED_MAX_N")) { m = atoi(v) < m ? atoi(v) : m; if (const char *c = strchr(v, ',')) m2 = atoi(c + 1); }
+		if (const char *v = getenv("CHAINDP_SEED_LAB_CAP")) cap = atoi(v) < cap ? atoi(v) & ~15 : cap;
+		if (m < 64) m = 64;
+		if (cap < 256) cap = 256;
 		while (m > 0 && chaindp::seed_sort_lds_bytes(m, 32, 8) > (size_t)lds_limit) m -= 512;
 		while (m2 > m && chaindp::seed_sort_lds_bytes(m2, 4, 2) > (size_t)lds_limit) m2 -= 512;
+		ctx->seed_lab_cap = cap;
 		ctx->seed_max_n = m; ctx->seed_max_n2 = m2;
 	}
 	HIP_TRY(ctx, chaindp::launch_seed_expand_sort(st, dix, flag, n_reads, n_mini, ctx->d_mini_off, ctx->d_mini, ctx->d_bid, ctx->d_qlen, ctx->seed,
-	                                              ctx->d_seeds, ctx->d_a, ctx->d_off, ctx->d_mini_pos, ctx->seed_max_n, ctx->seed_max_n2));
+	                                              ctx->d_seeds, ctx->d_a, ctx->d_off, ctx->d_mini_pos, ctx->seed_max_n, ctx->seed_max_n2,
+	                                              ctx->seed_lab_cap, (int64_t)totals[0]));
 	if (off) HIP_TRY(ctx, hipMemcpyAsync(off, ctx->d_off, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, st));
 	if (mini_pos_off) HIP_TRY(ctx, hipMemcpyAsync(mini_pos_off, ctx->d_mp_off, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, st));
 	if (rep_len && n_reads) HIP_TRY(ctx, hipMemcpyAsync(rep_len, ctx->d_rep_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));

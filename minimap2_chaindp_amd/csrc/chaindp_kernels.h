@@ -92,8 +92,8 @@ struct SeedScratch {                 // n = minimizers of the batch
 	unsigned long long *kept, *used; // n each: anchors / used minimizers per minimizer, scanned in place
 	unsigned long long *src, *mstate;// n each: where its hits are; hits | used << 32 | tandem << 33
 	unsigned long long *tile_tmp;    // scan scratch, n / 1024 + 2
-	unsigned long long *totals;      // 2: anchors, used minimizers
-	void *stacks;                    // (max_anchors / 64 + 2 R + 4) x 12 B for the per-read sort
+	unsigned long long *totals;      // 4: anchors, used minimizers, work items of the sort, spare
+	void *stacks;                    // (max_anchors / 64 + 2 R + 4) x 12 B: work items / range stacks of the per-read sort
 };
 // phase 1: probe, scans, per-read offsets and rep_len; the host then reads off[n_reads] (capacity check) and runs
 // phase 2: expand (anchors in generation order into d_unsorted, mini_pos) and the per-read radix_sort_128x into d_a
@@ -102,7 +102,8 @@ hipError_t launch_seed_collect(hipStream_t st, const SeedIndex &ix, int flag, in
                                int64_t *d_off, int64_t *d_mp_off, int32_t *d_rep_len);
 hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag, int64_t n_reads, int64_t n_mini,
                                    const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, const int32_t *d_qlen, SeedScratch sc,
-                                   void *d_unsorted, void *d_a, const int64_t *d_off, unsigned long long *d_mini_pos, int max_n, int max_n2);
+                                   void *d_unsorted, void *d_a, const int64_t *d_off, unsigned long long *d_mini_pos, int max_n, int max_n2,
+                                   int lab_cap, int64_t total);   // lab_cap: LDS bytes for digits in k_seed_sort_huge; total = d_off[n_reads]
 // LDS bytes of the per-read sort for reads of up to max_n anchors with `workers` bucket tables and `coop` wave-wide
 // histograms; the host picks the largest max_n (<= 8192; 32 workers, 8 histograms) and max_n2 (4 workers, 2 histograms)
 // that fit the device's LDS per workgroup

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void k_seed_reads(int64_t n_reads, int64_t n_mi
 	rep_len[r] = rl + rep_en - rep_st;
 }
 
-// Reads too large for the LDS sort below: the same procedure by one thread in global memory (slow, rare).
+// Reads too large even for k_seed_sort_huge below: the same procedure by one thread in global memory (slow; millions of anchors in one read).
 __global__ __launch_bounds__(64) void k_seed_sort_big(int64_t n_reads, int max_n, const int64_t *__restrict__ off, const ulonglong2 *__restrict__ src,
                                                       ulonglong2 *__restrict__ a, BtRange *__restrict__ stacks)
 {
@@ -212,6 +212,140 @@ __global__ __launch_bounds__(64) void k_seed_sort_big(int64_t n_reads, int max_n
 	if (n <= max_n) return;
 	for (int64_t i = 0; i < n; ++i) a[b + i] = src[b + i];
 	bt_radix_128x(a + b, (int32_t)n, stacks + b / 64 + 2 * r);                           // map.c:233
+}
+
+// Reads above what the LDS sort takes (more than max_n2 anchors): their top levels, one workgroup per read.
+// A level of the reference's sort (ksort.h:126-141) reads every element exactly once, at a bucket's head pointer, before
+// anything was stored there -- so the sequence of swaps depends on the DIGITS of the elements at their original places
+// only.  The workgroup writes those digits to LDS (one byte per anchor) and counts them, one lane replays the
+// reference's swap loop over the bytes alone and notes for every position which element ends there, and the
+// workgroup then moves the 16-byte anchors in one parallel pass.  Buckets that fit the LDS sort become work items for
+// it (k_seed_sort below takes them after the reads, at their shift), buckets of up to 64 anchors are insertion-sorted
+// by the thread that owns them (ksort.h:148), larger ones go round again.  Pending large ranges are disjoint and
+// each longer than min_n, so SEED_HUGE_STACK slots hold them for reads of up to SEED_HUGE_STACK x min_n anchors;
+// k_seed_sort_big keeps the rest.  A range with more anchors than LDS has bytes keeps its digits in global memory
+// (packed eight to a word in the scratch copy's y fields): same walk, global-memory latency per step.
+struct SeedItem { uint32_t beg_lo, len, beg_hi_shift; };           // anchors [beg, beg + len) of d_unsorted, to be sorted from `shift` down
+#define SEED_HUGE_STACK 320
+
+template <bool GLOBAL_DIGITS>
+__device__ __forceinline__ void seed_huge_walk(const uint8_t *lab, int *head, const int *tail, ulonglong2 *a_read, int rb)
+{
+	auto digit = [&](int pos) -> int {
+		const int i = pos - rb;
+		if (GLOBAL_DIGITS) return (int)(a_read[rb + (i >> 3)].y >> ((i & 7) * 8) & 0xff);
+		return (int)lab[i];
+	};
+	for (int d = 0; d < 256; ++d) {                                     // ksort.h:129-141 on digits; a_read[q].x = source of position q
+		int hd = head[d];
+		const int td = tail[d];
+		while (hd != td) {
+			int l = digit(hd);
+			if (l != d) {
+				int carry = hd;
+				do {
+					const int hp = head[l];
+					a_read[hp].x = (uint64_t)carry;
+					carry = hp;
+					head[l] = hp + 1;
+					l = digit(hp);
+				} while (l != d);
+				a_read[hd].x = (uint64_t)carry;
+			} else a_read[hd].x = (uint64_t)hd;
+			++hd;
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_seed_sort_huge(int64_t n_reads, int min_n, int max_n, int lab_cap, const int64_t *__restrict__ off,
+                                                        ulonglong2 *__restrict__ w, ulonglong2 *__restrict__ a, SeedItem *__restrict__ items,
+                                                        unsigned long long *__restrict__ n_items)
+{
+	extern __shared__ uint8_t huge_lds[];
+	uint8_t *lab = huge_lds;
+	int *head = (int*)(huge_lds + lab_cap);
+	int *tail = head + 256, *start = tail + 256;
+	unsigned int *hist = (unsigned int*)(start + 256);
+	int *stack = (int*)(hist + 256);                                   // SEED_HUGE_STACK x (beg, end, shift)
+	int *sp = stack + 3 * SEED_HUGE_STACK;
+	const int tid = threadIdx.x;
+	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+		const int64_t b = off[r];
+		const int64_t n64 = off[r + 1] - b;
+		if (n64 <= min_n || n64 > max_n) continue;
+		const int n = (int)n64;
+		ulonglong2 *wr = w + b, *ar = a + b;                            // wr: the read being sorted; ar: scratch during a level, a copy of wr between levels
+		for (int i = tid; i < n; i += 256) ar[i] = wr[i];
+		__syncthreads();
+		if (tid == 0) { stack[0] = 0; stack[1] = n; stack[2] = 56; sp[0] = 1; }
+		__syncthreads();
+		for (;;) {
+			const int top = sp[0];
+			if (top == 0) break;
+			const int rb = stack[3 * (top - 1)], re = stack[3 * (top - 1) + 1], sh = stack[3 * (top - 1) + 2];
+			const int len = re - rb;
+			const bool global_digits = len > lab_cap;
+			__syncthreads();
+			if (tid == 0) sp[0] = top - 1;
+			hist[tid] = 0;
+			__syncthreads();
+			if (!global_digits) {
+				for (int i = tid; i < len; i += 256) {
+					const int d = (int)(wr[rb + i].x >> sh & 0xff);
+					lab[i] = (uint8_t)d;
+					atomicAdd(&hist[d], 1u);                            // ksort.h:126
+				}
+			} else {
+				for (int g = tid; g * 8 < len; g += 256) {
+					uint64_t pack = 0;
+					for (int j = 0; j < 8 && g * 8 + j < len; ++j) {
+						const uint64_t d = wr[rb + g * 8 + j].x >> sh & 0xff;
+						pack |= d << (8 * j);
+						atomicAdd(&hist[(int)d], 1u);
+					}
+					ar[rb + g].y = pack;
+				}
+			}
+			__syncthreads();
+			const int next = sh > 8 ? sh - 8 : 0;
+			if (hist[(int)(wr[rb].x >> sh & 0xff)] == (unsigned int)len) {  // one bucket: the pass moves nothing
+				if (global_digits) for (int g = tid; g * 8 < len; g += 256) ar[rb + g].y = wr[rb + g].y;
+				if (tid == 0 && sh) { const int k = sp[0]; stack[3 * k] = rb; stack[3 * k + 1] = re; stack[3 * k + 2] = next; sp[0] = k + 1; }
+				__syncthreads();
+				continue;
+			}
+			if (tid == 0) {
+				int acc = rb;
+				for (int d = 0; d < 256; ++d) { head[d] = acc; start[d] = acc; acc += (int)hist[d]; tail[d] = acc; }
+				if (global_digits) seed_huge_walk<true>(lab, head, tail, ar, rb);
+				else seed_huge_walk<false>(lab, head, tail, ar, rb);
+			}
+			__syncthreads();
+			for (int i = rb + tid; i < re; i += 256) ar[i] = wr[(int)ar[i].x];
+			__syncthreads();
+			for (int i = rb + tid; i < re; i += 256) wr[i] = ar[i];
+			if (sh) {                                                       // ksort.h:143-149
+				const int sb = start[tid], se = tail[tid], l = se - sb;
+				if (l > min_n) {
+					const int k = atomicAdd(&sp[0], 1);
+					stack[3 * k] = sb; stack[3 * k + 1] = se; stack[3 * k + 2] = next;
+				} else if (l > 64) {
+					const unsigned long long k = atomicAdd(n_items, 1ull);
+					const uint64_t gb = (uint64_t)(b + sb);
+					items[k] = SeedItem{(uint32_t)gb, (uint32_t)l, (uint32_t)(gb >> 32) << 8 | (uint32_t)next};
+				}
+			}
+			__syncthreads();
+			if (sh) {                                                       // small buckets after the moves above are visible
+				const int sb = start[tid], se = tail[tid], l = se - sb;
+				if (l > 1 && l <= 64) {
+					bt_insertion(wr + sb, wr + se);
+					for (int i = sb; i < se; ++i) ar[i] = wr[i];
+				}
+			}
+			__syncthreads();
+		}
+	}
 }
 
 // radix_sort_128x (ksort.h:101-151) of one read by one wave, in LDS, on (key, original index) pairs.  The reference's
@@ -242,7 +376,8 @@ __device__ __forceinline__ void seed_isort(uint64_t *key, uint16_t *idx, int beg
 
 // takes the reads with min_n < anchors <= max_n; `workers` lanes (a power of two <= 64) have bucket tables
 __global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int min_n, int max_n, int workers, int coop, int try_network, const int64_t *__restrict__ off,
-                                                  const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ a)
+                                                  const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ a,
+                                                  const SeedItem *__restrict__ items, const unsigned long long *__restrict__ n_items)
 {
 	extern __shared__ uint64_t seed_lds[];
 	const int lane = threadIdx.x;
@@ -252,9 +387,15 @@ __global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int min_n, in
 	SeedRange *qbase = (SeedRange*)(idx + max_n + workers * 512);
 	int *qn = (int*)(qbase + 2 * SEED_Q);                              // [parity][0 = big ranges, 1 = small ranges]
 	unsigned int *hist = (unsigned int*)(qn + 4);                      // coop x 256: digit counts of a round's first big ranges, made by all lanes
-	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
-		const int64_t b = off[r];
-		const int64_t n64 = off[r + 1] - b;
+	const int64_t n_units = n_reads + (int64_t)*n_items;               // whole reads, then the buckets k_seed_sort_huge left
+	for (int64_t r = blockIdx.x; r < n_units; r += gridDim.x) {
+		int64_t b, n64;
+		int shift0 = 56;
+		if (r < n_reads) { b = off[r]; n64 = off[r + 1] - b; }
+		else {
+			const SeedItem it = items[r - n_reads];
+			b = (int64_t)((uint64_t)(it.beg_hi_shift >> 8) << 32 | it.beg_lo); n64 = it.len; shift0 = (int)(it.beg_hi_shift & 0xff);
+		}
 		if (n64 <= min_n || n64 > max_n) continue;
 		const int n = (int)n64;
 		__syncthreads();
@@ -298,7 +439,7 @@ __global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int min_n, in
 			}
 		}
 		for (int i = lane; i < n; i += 64) { key[i] = src[b + i].x; idx[i] = (uint16_t)i; }
-		if (lane == 0) { qbase[0] = SeedRange{0, (uint16_t)n, 56, 0}; qn[0] = 1; qn[1] = 0; qn[2] = 0; qn[3] = 0; }
+		if (lane == 0) { qbase[0] = SeedRange{0, (uint16_t)n, (uint16_t)shift0, 0}; qn[0] = 1; qn[1] = 0; qn[2] = 0; qn[3] = 0; }
 		__syncthreads();
 		for (int which = 0;; which ^= 1) {
 			SeedRange *cur = qbase + which * SEED_Q, *nxt = qbase + (which ^ 1) * SEED_Q;
@@ -398,20 +539,35 @@ hipError_t launch_seed_collect(hipStream_t st, const SeedIndex &ix, int flag, in
 
 hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag, int64_t n_reads, int64_t n_mini,
                                    const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, const int32_t *d_qlen, SeedScratch sc,
-                                   void *d_unsorted, void *d_a, const int64_t *d_off, unsigned long long *d_mini_pos, int max_n, int max_n2)
+                                   void *d_unsorted, void *d_a, const int64_t *d_off, unsigned long long *d_mini_pos, int max_n, int max_n2,
+                                   int lab_cap, int64_t total)
 {
 	if (n_mini > 0) {
 		hipLaunchKernelGGL(k_seed_expand, dim3((unsigned)((n_mini + 255) / 256)), dim3(256), 0, st, ix, flag, n_reads, n_mini, d_mini_off,
 		                   (const ulonglong2*)d_mini, d_bid, d_qlen, sc.kept, sc.used, sc.src, sc.mstate, (ulonglong2*)d_unsorted, d_mini_pos);
 	}
 	if (n_reads > 0) {
-		// the LDS sort takes reads of up to max_n anchors (what fits the device's LDS per workgroup); anything larger goes
-		// to the one-thread version
-		const unsigned grid = (unsigned)(n_reads < 256 * 8 ? n_reads : 256 * 8);
+		// the LDS sort takes reads of up to max_n / max_n2 anchors (what fits the device's LDS per workgroup); larger reads
+		// have their top levels done by k_seed_sort_huge, which hands the buckets that fit back to the LDS sort as work items
+		const int cap = max_n2 > max_n ? max_n2 : max_n;
+		const int64_t huge_max64 = (int64_t)SEED_HUGE_STACK * cap;
+		const int huge_max = cap <= 0 ? 0 : (int)(huge_max64 < 0x7fffffff ? huge_max64 : 0x7fffffff);
+		SeedItem *items = (SeedItem*)sc.stacks;
+		unsigned long long *n_items = sc.totals + 2;
+		hipError_t e = hipMemsetAsync(n_items, 0, 8, st);
+		if (e != hipSuccess) return e;
+		if (cap > 0 && total > cap) {
+			const unsigned hgrid = (unsigned)(n_reads < 256 ? n_reads : 256);
+			hipLaunchKernelGGL(k_seed_sort_huge, dim3(hgrid), dim3(256), (size_t)lab_cap + 4096 + 12 * SEED_HUGE_STACK + 16, st, n_reads, cap, huge_max, lab_cap,
+			                   d_off, (ulonglong2*)d_unsorted, (ulonglong2*)d_a, items, n_items);
+		}
+		const int64_t units = n_reads + (total > cap && cap > 0 ? total / 65 : 0);
+		const unsigned grid = (unsigned)(units < 256 * 8 ? units : 256 * 8);
 		const int try_network = getenv("CHAINDP_SEED_FORCE_EXACT") == nullptr;      // measurement switch: every read through the reference's procedure
-		if (max_n > 0) hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(64), seed_sort_lds_bytes(max_n, 32, 8), st, n_reads, 0, max_n, 32, 8, try_network, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a);
-		if (max_n2 > max_n) hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(64), seed_sort_lds_bytes(max_n2, 4, 2), st, n_reads, max_n, max_n2, 4, 2, try_network, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a);
-		hipLaunchKernelGGL(k_seed_sort_big, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, st, n_reads, max_n2 > max_n ? max_n2 : max_n, d_off, (const ulonglong2*)d_unsorted,
+		if (max_n > 0) hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(64), seed_sort_lds_bytes(max_n, 32, 8), st, n_reads, 0, max_n, 32, 8, try_network, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a, items, n_items);
+		if (max_n2 > max_n) hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(64), seed_sort_lds_bytes(max_n2, 4, 2), st, n_reads, max_n, max_n2, 4, 2, try_network, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a, items, n_items);
+		// reads beyond SEED_HUGE_STACK x cap anchors: one thread each in global memory
+		hipLaunchKernelGGL(k_seed_sort_big, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, st, n_reads, huge_max, d_off, (const ulonglong2*)d_unsorted,
 		                   (ulonglong2*)d_a, (BtRange*)sc.stacks);
 	}
 	return hipGetLastError();

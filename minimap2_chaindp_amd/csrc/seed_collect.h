@@ -29,8 +29,8 @@ public:
 	void clear();
 	// mm_idx_get (index.c:221-238) over the image: positions of minimizer `minier`, *n of them (0 if absent)
 	const uint64_t *get(uint64_t minier, int *n) const;
-	void prefetch(uint64_t minier, int level) const;
-	const std::vector<uint8_t> &blob(int k) const { return k == 0 ? B_ : k == 1 ? H_ : k == 2 ? V_ : P_; }   // 0..3 = B, H, V, P           // level 0: bucket entry; 1: first hash group and value
+	void prefetch(uint64_t minier, int level) const;   // level 0: bucket entry; 1: first hash group and value
+	const std::vector<uint8_t> &blob(int k) const { return k == 0 ? B_ : k == 1 ? H_ : k == 2 ? V_ : P_; }   // 0..3 = B, H, V, P
 private:
 	void seal();
 	std::vector<uint8_t> B_, H_, V_, P_;

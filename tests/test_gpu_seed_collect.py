@@ -137,12 +137,7 @@ def _build_image(rng, n_keys, max_cnt, b_bits=6):
     return blobs, keys
 
 
-@pytest.mark.parametrize("seed,max_cnt,n_mini,rep_pct", [(1, 3, 400, 0), (2, 6, 900, 20), (3, 40, 500, 30), (4, 12, 2500, 40), (5, 90, 400, 25), (6, 90, 1500, 35)])
-def test_gpu_seed_collection_against_host_statement_on_synthetic_images(seed, max_cnt, n_mini, rep_pct):
-    """Random index images and minimizer lists with many repeated minimizers (equal x in the anchors) and reads of a few
-    hundred to > 14 k anchors: all three sort paths (bitonic, the reference's procedure in LDS with 32 / 4 bucket tables, one
-    thread in global memory).  Expected values come from the host statement (csrc/seed_collect.cpp), itself pinned against
-    the reference on the CPU tier."""
+def _synthetic_case(seed, max_cnt, n_mini, rep_pct):
     from minimap2_chaindp_amd import fpga
     rng = np.random.default_rng(seed)
     blobs, keys = _build_image(rng, 3000, max_cnt)
@@ -167,14 +162,41 @@ def test_gpu_seed_collection_against_host_statement_on_synthetic_images(seed, ma
     fpga.lib().fpga_finalize()
     with chaindp.Device(0, max_anchors=1 << 21, max_reads=64) as d:
         ix = d.load_index(blobs)
-        off, a, rep_len, mpo, mp = d.collect_seeds(ix, flag, max_occ, np.array(mini_off, np.int64), mini, np.array(bid, np.uint32), np.array(qlen, np.int32))
+        import time
+        for _ in range(2):
+            t0 = time.time()
+            off, a, rep_len, mpo, mp = d.collect_seeds(ix, flag, max_occ, np.array(mini_off, np.int64), mini, np.array(bid, np.uint32), np.array(qlen, np.int32))
+            dt = time.time() - t0
     sizes = [len(e[0]) for e in exp]
     assert list(np.diff(off)) == sizes, (sizes, list(np.diff(off)))
     for r in range(n_reads):
         assert np.array_equal(a[off[r]:off[r + 1]], exp[r][0]), (seed, r, sizes[r], "anchors")
         assert rep_len[r] == exp[r][1] and np.array_equal(mp[mpo[r]:mpo[r + 1]], exp[r][2]), (seed, r)
     ties = sum(int((np.diff(e[0][:, 0]) == 0).sum()) for e in exp if len(e[0]) > 1)
-    print(f"\nseed {seed}: anchors per read {sizes}, equal-x pairs {ties}")
+    print(f"\nseed {seed}: anchors per read {sizes}, equal-x pairs {ties}, {dt * 1e3:.1f} ms with transfers")
+
+
+@pytest.mark.parametrize("seed,max_cnt,n_mini,rep_pct", [(1, 3, 400, 0), (2, 6, 900, 20), (3, 40, 500, 30), (4, 12, 2500, 40), (5, 90, 400, 25), (6, 90, 1500, 35),
+                                                         (7, 90, 9000, 30)])
+def test_gpu_seed_collection_against_host_statement_on_synthetic_images(seed, max_cnt, n_mini, rep_pct):
+    """Random index images and minimizer lists with many repeated minimizers (equal x in the anchors) and reads of a few
+    hundred to > 200 k anchors: every sort path (bitonic, the reference's procedure in LDS with 32 / 4 bucket tables, and for
+    reads beyond the LDS sort the top levels by k_seed_sort_huge with digits in LDS or, past ~150 k anchors, in global
+    memory).  Expected values come from the host statement (csrc/seed_collect.cpp), itself pinned against the reference
+    on the CPU tier."""
+    _synthetic_case(seed, max_cnt, n_mini, rep_pct)
+
+
+@pytest.mark.parametrize("limits,lab_cap", [("256,512", "1024"), ("128,128", "100000"), ("1024,4096", "4096")])
+@pytest.mark.parametrize("seed,max_cnt,n_mini,rep_pct", [(2, 6, 900, 20), (4, 12, 2500, 40), (6, 90, 1500, 35)])
+def test_gpu_seed_collection_with_small_sort_limits(monkeypatch, limits, lab_cap, seed, max_cnt, n_mini, rep_pct):
+    """The same cases with the LDS sort's limits turned down (test switches read when a context first collects seeds), so
+    that ordinary reads take the paths made for very large ones: top levels by k_seed_sort_huge (digits in LDS and in
+    global memory, nested large buckets, single-digit levels), buckets handed to both LDS configurations as work items,
+    and, beyond 320 x the limit, the one-thread kernel."""
+    monkeypatch.setenv("CHAINDP_SEED_MAX_N", limits)
+    monkeypatch.setenv("CHAINDP_SEED_LAB_CAP", lab_cap)
+    _synthetic_case(seed, max_cnt, n_mini, rep_pct)
 
 
 def test_seed_collection_argument_errors(dev):
