@@ -8,11 +8,12 @@
 //   (two exclusive scans: anchors before each minimizer, used minimizers before each minimizer)
 //   k_seed_expand  thread per minimizer: writes its surviving hits as anchors (map.c:197-231), in the reference's
 //                  generation order, and its mini_pos entry
-//   k_seed_reads   thread per read: anchor / mini_pos offsets of the read and rep_len (the interval merge of
-//                  map.c:127-133 is sequential in the minimizers, 2-3 k steps)
+//   k_seed_reads   wave per read: anchor / mini_pos offsets of the read and rep_len (the interval merge of
+//                  map.c:127-133, one term per skipped minimizer)
 //   k_seed_sort    wave per read, in LDS: the order radix_sort_128x (ksort.h:101-151) gives equal x is input to the
 //                  chaining DP, so a read with equal keys is sorted by the reference's procedure step by step; a
-//                  read without (the common case) by a bitonic network.  k_seed_sort_big: reads too large for LDS.
+//                  read without (the common case) by a bitonic network.
+//   k_seed_sort_huge  workgroup per read too large for LDS: top levels in global memory, buckets back to k_seed_sort
 // Image layout: see csrc/seed_collect.h (the host-side statement of the same lookup, pinned on the CPU tier).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -178,27 +179,45 @@ __global__ __launch_bounds__(256) void k_seed_expand(SeedIndex ix, int flag, int
 	}
 }
 
-__global__ __launch_bounds__(64) void k_seed_reads(int64_t n_reads, int64_t n_mini, const int64_t *__restrict__ mini_off,
-                                                   const ulonglong2 *__restrict__ mini, const unsigned long long *__restrict__ kept_pos,
-                                                   const unsigned long long *__restrict__ used_pos, const unsigned long long *__restrict__ mstate,
-                                                   const unsigned long long *__restrict__ totals, int64_t *__restrict__ off,
-                                                   int64_t *__restrict__ mp_off, int32_t *__restrict__ rep_len)
+// One wave per read.  rep_len (map.c:116,127-133,143) is the length of the union of the skipped minimizers' intervals,
+// kept by the reference as (rep_st, rep_en) with rep_en always the end of the last skipped minimizer: a minimizer
+// starts a new interval when its start lies beyond the previous skipped minimizer's end, and the sum telescopes to
+// sum_i (en_i - (st_i > en_prev ? st_i : en_prev)) with en_prev = 0 before the first -- one term per minimizer.
+__global__ __launch_bounds__(256) void k_seed_reads(int64_t n_reads, int64_t n_mini, const int64_t *__restrict__ mini_off,
+                                                    const ulonglong2 *__restrict__ mini, const unsigned long long *__restrict__ kept_pos,
+                                                    const unsigned long long *__restrict__ used_pos, const unsigned long long *__restrict__ mstate,
+                                                    const unsigned long long *__restrict__ totals, int64_t *__restrict__ off,
+                                                    int64_t *__restrict__ mp_off, int32_t *__restrict__ rep_len)
 {
-	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	if (r > n_reads) return;
-	if (r == n_reads) { off[r] = (int64_t)totals[0]; mp_off[r] = (int64_t)totals[1]; return; }
+	if (r == n_reads) { if (lane == 0) { off[r] = (int64_t)totals[0]; mp_off[r] = (int64_t)totals[1]; } return; }
 	const int64_t b = mini_off[r], e = mini_off[r + 1];
-	off[r] = b < n_mini ? (int64_t)kept_pos[b] : (int64_t)totals[0];
-	mp_off[r] = b < n_mini ? (int64_t)used_pos[b] : (int64_t)totals[1];
-	int rep_st = 0, rep_en = 0, rl = 0;                                                  // map.c:116,127-133,143
-	for (int64_t i = b; i < e; ++i) {
-		if (mstate[i] >> 32 & 1) continue;
-		const ulonglong2 p = mini[i];
-		const int en = (int)((uint32_t)p.y >> 1) + 1, st = en - (int)(p.x & 0xff);
-		if (st > rep_en) { rl += rep_en - rep_st; rep_st = st; rep_en = en; }
-		else rep_en = en;
+	if (lane == 0) {
+		off[r] = b < n_mini ? (int64_t)kept_pos[b] : (int64_t)totals[0];
+		mp_off[r] = b < n_mini ? (int64_t)used_pos[b] : (int64_t)totals[1];
 	}
-	rep_len[r] = rl + rep_en - rep_st;
+	int prev_en = 0, sum = 0;
+	for (int64_t base = b; base < e; base += 64) {
+		const int64_t i = base + lane;
+		bool skipped = false;
+		int en = 0, st = 0;
+		if (i < e && !(mstate[i] >> 32 & 1)) {
+			const ulonglong2 p = mini[i];
+			skipped = true;
+			en = (int)((uint32_t)p.y >> 1) + 1; st = en - (int)(p.x & 0xff);
+		}
+		const unsigned long long m = __ballot(skipped);
+		if (m == 0) continue;
+		const unsigned long long below = m & ((1ull << lane) - 1);
+		int pe = __shfl(en, below ? 63 - __clzll((long long)below) : 0);
+		if (!below) pe = prev_en;
+		if (skipped) sum += st > pe ? en - st : en - pe;
+		prev_en = __shfl(en, 63 - __clzll((long long)m));
+	}
+	for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+	if (lane == 0) rep_len[r] = sum;
 }
 
 // Reads too large even for k_seed_sort_huge below: the same procedure by one thread in global memory (slow; millions of anchors in one read).
@@ -355,7 +374,7 @@ __global__ __launch_bounds__(256) void k_seed_sort_huge(int64_t n_reads, int min
 // pointers live in LDS (16-bit: a read here has at most max_n <= 65535 anchors), and a level on which every key of
 // the range has the same digit is skipped (the reference's pass over it moves nothing).
 // LDS: keys[max_n] u64 | idx[max_n] u16 | workers x (head[256], tail[256]) u16 | two queues of SEED_Q ranges | 4 counters
-// (32 workers for reads of up to 8192 anchors; the same kernel with 4 workers takes reads of up to ~14 k).
+// (32 workers for reads of up to 8192 anchors, 4 workers for reads of up to ~14 k; chosen per read inside one launch).
 // A queue keeps its first SEED_QBIG slots for ranges of more than 64 anchors (at most max_n / 65 exist at a time, so
 // they always fit); small ranges that find the rest full are insertion-sorted on the spot by the lane that made them.
 struct SeedRange { uint16_t beg, end; uint16_t shift, pad; };
@@ -374,19 +393,14 @@ __device__ __forceinline__ void seed_isort(uint64_t *key, uint16_t *idx, int beg
 	}
 }
 
-// takes the reads with min_n < anchors <= max_n; `workers` lanes (a power of two <= 64) have bucket tables
-__global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int min_n, int max_n, int workers, int coop, int try_network, const int64_t *__restrict__ off,
+// takes the reads (and work items) of up to max_n2 anchors: with 32 bucket tables and 8 wave-wide histograms up to max_n
+// anchors, with 4 and 2 above (the LDS layout is chosen per read; the launch reserves the larger of the two)
+__global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int max_n, int max_n2, int try_network, const int64_t *__restrict__ off,
                                                   const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ a,
                                                   const SeedItem *__restrict__ items, const unsigned long long *__restrict__ n_items)
 {
 	extern __shared__ uint64_t seed_lds[];
 	const int lane = threadIdx.x;
-	uint64_t *key = seed_lds;
-	uint16_t *idx = (uint16_t*)(key + max_n);
-	uint16_t *head = idx + max_n + (lane & (workers - 1)) * 512, *tail = head + 256;
-	SeedRange *qbase = (SeedRange*)(idx + max_n + workers * 512);
-	int *qn = (int*)(qbase + 2 * SEED_Q);                              // [parity][0 = big ranges, 1 = small ranges]
-	unsigned int *hist = (unsigned int*)(qn + 4);                      // coop x 256: digit counts of a round's first big ranges, made by all lanes
 	const int64_t n_units = n_reads + (int64_t)*n_items;               // whole reads, then the buckets k_seed_sort_huge left
 	for (int64_t r = blockIdx.x; r < n_units; r += gridDim.x) {
 		int64_t b, n64;
@@ -396,8 +410,15 @@ __global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int min_n, in
 			const SeedItem it = items[r - n_reads];
 			b = (int64_t)((uint64_t)(it.beg_hi_shift >> 8) << 32 | it.beg_lo); n64 = it.len; shift0 = (int)(it.beg_hi_shift & 0xff);
 		}
-		if (n64 <= min_n || n64 > max_n) continue;
+		if (n64 > (max_n2 > max_n ? max_n2 : max_n)) continue;
 		const int n = (int)n64;
+		const int cap_n = n <= max_n ? max_n : max_n2, workers = n <= max_n ? 32 : 4, coop = n <= max_n ? 8 : 2;
+		uint64_t *key = seed_lds;
+		uint16_t *idx = (uint16_t*)(key + cap_n);
+		uint16_t *head = idx + cap_n + (lane & (workers - 1)) * 512, *tail = head + 256;
+		SeedRange *qbase = (SeedRange*)(idx + cap_n + workers * 512);
+		int *qn = (int*)(qbase + 2 * SEED_Q);                              // [parity][0 = big ranges, 1 = small ranges]
+		unsigned int *hist = (unsigned int*)(qn + 4);                      // coop x 256: digit counts of a round's first big ranges, made by all lanes
 		__syncthreads();
 		// A sorted order is unique when all keys differ, and then any sort will do: try a bitonic network first (all 64
 		// lanes busy, ~0.1 ms) and keep its result unless two neighbours are equal; only reads with equal x go through the
@@ -532,7 +553,7 @@ hipError_t launch_seed_collect(hipStream_t st, const SeedIndex &ix, int flag, in
 	}
 	if ((e = launch_scan_u64(st, n_mini, sc.kept, sc.tile_tmp, sc.totals)) != hipSuccess) return e;
 	if ((e = launch_scan_u64(st, n_mini, sc.used, sc.tile_tmp, sc.totals + 1)) != hipSuccess) return e;
-	hipLaunchKernelGGL(k_seed_reads, dim3((unsigned)((n_reads + 1 + 63) / 64)), dim3(64), 0, st, n_reads, n_mini, d_mini_off, (const ulonglong2*)d_mini,
+	hipLaunchKernelGGL(k_seed_reads, dim3((unsigned)((n_reads + 1 + 3) / 4)), dim3(256), 0, st, n_reads, n_mini, d_mini_off, (const ulonglong2*)d_mini,
 	                   sc.kept, sc.used, sc.mstate, sc.totals, d_off, d_mp_off, d_rep_len);
 	return hipGetLastError();
 }
@@ -564,8 +585,11 @@ hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag
 		const int64_t units = n_reads + (total > cap && cap > 0 ? total / 65 : 0);
 		const unsigned grid = (unsigned)(units < 256 * 8 ? units : 256 * 8);
 		const int try_network = getenv("CHAINDP_SEED_FORCE_EXACT") == nullptr;      // measurement switch: every read through the reference's procedure
-		if (max_n > 0) hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(64), seed_sort_lds_bytes(max_n, 32, 8), st, n_reads, 0, max_n, 32, 8, try_network, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a, items, n_items);
-		if (max_n2 > max_n) hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(64), seed_sort_lds_bytes(max_n2, 4, 2), st, n_reads, max_n, max_n2, 4, 2, try_network, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a, items, n_items);
+		if (cap > 0) {
+			size_t lds = seed_sort_lds_bytes(max_n, 32, 8);
+			if (max_n2 > max_n && seed_sort_lds_bytes(max_n2, 4, 2) > lds) lds = seed_sort_lds_bytes(max_n2, 4, 2);
+			hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(64), lds, st, n_reads, max_n, max_n2, try_network, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a, items, n_items);
+		}
 		// reads beyond SEED_HUGE_STACK x cap anchors: one thread each in global memory
 		hipLaunchKernelGGL(k_seed_sort_big, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, st, n_reads, huge_max, d_off, (const ulonglong2*)d_unsorted,
 		                   (ulonglong2*)d_a, (BtRange*)sc.stacks);
