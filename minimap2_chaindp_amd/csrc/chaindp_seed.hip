@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include "chaindp_kernels.h"
 #include "chaindp_rsort.h"
+#include "chaindp_wave.h"
 
 namespace chaindp {
 
@@ -373,13 +374,14 @@ __global__ __launch_bounds__(256) void k_seed_sort_huge(int64_t n_reads, int min
 // independent, so after the first one or two levels up to 32 lanes work on as many ranges at a time, the histograms and bucket
 // pointers live in LDS (16-bit: a read here has at most max_n <= 65535 anchors), and a level on which every key of
 // the range has the same digit is skipped (the reference's pass over it moves nothing).
-// LDS: keys[max_n] u64 | idx[max_n] u16 | workers x (head[256], tail[256]) u16 | two queues of SEED_Q ranges | 4 counters
-// (32 workers for reads of up to 8192 anchors, 4 workers for reads of up to ~14 k; chosen per read inside one launch).
-// A queue keeps its first SEED_QBIG slots for ranges of more than 64 anchors (at most max_n / 65 exist at a time, so
-// they always fit); small ranges that find the rest full are insertion-sorted on the spot by the lane that made them.
+// LDS: keys[max_n] u64 | idx[max_n] u16 | workers x (head[256], tail[256]) u16 | two queues of ranges | counters and flags |
+// coop x 256 digit counts | digits[max_n] u8
+// (32 workers for reads of up to 8192 anchors, 4 workers for reads of up to ~13 k; chosen per read inside one launch).
+// A queue keeps its first max_n / 65 + 2 slots for ranges of more than 64 anchors (they are disjoint, so they always fit);
+// small ranges that find the rest full are insertion-sorted on the spot by the lane that made them.
 struct SeedRange { uint16_t beg, end; uint16_t shift, pad; };
-#define SEED_QBIG 136
-#define SEED_Q (SEED_QBIG + 1024)
+__host__ __device__ inline int seed_big_slots(int max_n) { return max_n / 65 + 2; }                    // queue slots for ranges of > 64 anchors: they are disjoint
+__host__ __device__ inline int seed_small_slots(int workers) { return workers >= 32 ? 1024 : 256; }   // queue slots for ranges of <= 64 anchors
 
 __device__ __forceinline__ void seed_isort(uint64_t *key, uint16_t *idx, int beg, int end)    // ksort.h:107-117
 {
@@ -395,7 +397,8 @@ __device__ __forceinline__ void seed_isort(uint64_t *key, uint16_t *idx, int beg
 
 // takes the reads (and work items) of up to max_n2 anchors: with 32 bucket tables and 8 wave-wide histograms up to max_n
 // anchors, with 4 and 2 above (the LDS layout is chosen per read; the launch reserves the larger of the two)
-__global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int max_n, int max_n2, int try_network, const int64_t *__restrict__ off,
+#define SEED_TPB 256
+__global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max_n, int max_n2, int try_network, const int64_t *__restrict__ off,
                                                   const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ a,
                                                   const SeedItem *__restrict__ items, const unsigned long long *__restrict__ n_items)
 {
@@ -412,36 +415,48 @@ __global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int max_n, in
 		}
 		if (n64 > (max_n2 > max_n ? max_n2 : max_n)) continue;
 		const int n = (int)n64;
-		const int cap_n = n <= max_n ? max_n : max_n2, workers = n <= max_n ? 32 : 4, coop = n <= max_n ? 8 : 2;
+		const int cap_n = n <= max_n ? max_n : max_n2;
+		const int q_big = seed_big_slots(cap_n), q_slots = q_big + seed_small_slots(n <= max_n ? 32 : 4);
+		const int wave = lane >> 6, wl = lane & 63;
 		uint64_t *key = seed_lds;
 		uint16_t *idx = (uint16_t*)(key + cap_n);
-		uint16_t *head = idx + cap_n + (lane & (workers - 1)) * 512, *tail = head + 256;
-		SeedRange *qbase = (SeedRange*)(idx + cap_n + workers * 512);
-		int *qn = (int*)(qbase + 2 * SEED_Q);                              // [parity][0 = big ranges, 1 = small ranges]
-		unsigned int *hist = (unsigned int*)(qn + 4);                      // coop x 256: digit counts of a round's first big ranges, made by all lanes
+		uint16_t *head = idx + cap_n + wave * 768, *tail = head + 256, *start = tail + 256;   // one set of bucket tables per wave
+		unsigned int *cnt = (unsigned int*)(idx + cap_n + (SEED_TPB / 64) * 768) + wave * 256;   // and one set of digit counts
+		SeedRange *qbase = (SeedRange*)(cnt - wave * 256 + (SEED_TPB / 64) * 256);
+		int *qn = (int*)(qbase + 2 * q_slots);                             // [parity][0 = big ranges, 1 = small ranges]
+		uint8_t *lab = (uint8_t*)(qn + 4);                                 // cap_n: the current digit of every position
+		ulonglong2 *ag = a + b;                                            // this read's output range doubles as scratch until the final gather
 		__syncthreads();
-		// A sorted order is unique when all keys differ, and then any sort will do: try a bitonic network first (all 64
-		// lanes busy, ~0.1 ms) and keep its result unless two neighbours are equal; only reads with equal x go through the
+		// A sorted order is unique when all keys differ, and then any sort will do: try a bitonic network first (the whole
+		// workgroup busy) and keep its result unless two neighbours are equal; only reads with equal x go through the
 		// reference's procedure below (whose serial top levels take milliseconds).
 		int pow2 = 64;
 		while (pow2 < n) pow2 <<= 1;
 		if (try_network) {
 			// bitonic network in its all-ascending form (first step of a merge compares mirror positions), so that the
 			// virtual +inf padding behind the n real keys never has to move and needs no storage
-			for (int i = lane; i < n; i += 64) { key[i] = src[b + i].x; idx[i] = (uint16_t)i; }
+			for (int i = lane; i < n; i += SEED_TPB) { key[i] = src[b + i].x; idx[i] = (uint16_t)i; }
 			if (lane == 0) qn[0] = 0;
 			__syncthreads();
 			for (int k = 2; k <= pow2; k <<= 1) {
 				for (int j = k >> 1; j > 0; j >>= 1) {
 					const bool mirror = j == k >> 1;
-					for (int t = lane; t < pow2 / 2; t += 64) {
-						const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-						const int l = mirror ? (i | (k - 1)) - (i & (j - 1)) : i | j;         // mirror: block end minus offset
-						if (l < n) {
-							const uint64_t ki = key[i], kl = key[l];
-							if (ki > kl) {
-								const uint16_t ti = idx[i]; idx[i] = idx[l]; idx[l] = ti;
-								key[i] = kl; key[l] = ki;
+					for (int t0 = lane; t0 < pow2 / 2; t0 += 4 * SEED_TPB) {              // four disjoint pairs in flight per thread
+						int pi[4], pl[4];
+						uint64_t ki[4], kl[4];
+#pragma unroll
+						for (int u = 0; u < 4; ++u) {
+							const int t = t0 + u * SEED_TPB;
+							pi[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+							pl[u] = mirror ? (pi[u] | (k - 1)) - (pi[u] & (j - 1)) : pi[u] | j;   // mirror: block end minus offset
+							if (t >= pow2 / 2 || pl[u] >= n) pl[u] = -1;
+							else { ki[u] = key[pi[u]]; kl[u] = key[pl[u]]; }
+						}
+#pragma unroll
+						for (int u = 0; u < 4; ++u) {
+							if (pl[u] >= 0 && ki[u] > kl[u]) {
+								const uint16_t ti = idx[pi[u]]; idx[pi[u]] = idx[pl[u]]; idx[pl[u]] = ti;
+								key[pi[u]] = kl[u]; key[pl[u]] = ki[u];
 							}
 						}
 					}
@@ -449,97 +464,116 @@ __global__ __launch_bounds__(64) void k_seed_sort(int64_t n_reads, int max_n, in
 				}
 			}
 			int ties = 0;
-			for (int i = lane; i + 1 < n; i += 64) ties |= key[i] == key[i + 1];
+			for (int i = lane; i + 1 < n; i += SEED_TPB) ties |= key[i] == key[i + 1];
 			if (ties) qn[0] = 1;
 			__syncthreads();
 			const bool has_ties = qn[0] != 0;
 			__syncthreads();
 			if (!has_ties) {
-				for (int i = lane; i < n; i += 64) a[b + i] = src[b + idx[i]];
+				for (int i = lane; i < n; i += SEED_TPB) a[b + i] = src[b + idx[i]];
 				continue;
 			}
 		}
-		for (int i = lane; i < n; i += 64) { key[i] = src[b + i].x; idx[i] = (uint16_t)i; }
+		for (int i = lane; i < n; i += SEED_TPB) { key[i] = src[b + i].x; idx[i] = (uint16_t)i; }
 		if (lane == 0) { qbase[0] = SeedRange{0, (uint16_t)n, (uint16_t)shift0, 0}; qn[0] = 1; qn[1] = 0; qn[2] = 0; qn[3] = 0; }
 		__syncthreads();
 		for (int which = 0;; which ^= 1) {
-			SeedRange *cur = qbase + which * SEED_Q, *nxt = qbase + (which ^ 1) * SEED_Q;
+			SeedRange *cur = qbase + which * q_slots, *nxt = qbase + (which ^ 1) * q_slots;
 			int *ncnt = qn + 2 * (which ^ 1);
-			const int n_big = qn[2 * which], n_small = min(qn[2 * which + 1], SEED_Q - SEED_QBIG);
+			const int n_big = qn[2 * which], n_small = min(qn[2 * which + 1], q_slots - q_big);
 			if (n_big + n_small == 0) break;
-			// the top levels have one or two ranges of thousands of keys and a single lane each to permute them: at least
-			// their digit counts (ksort.h:126) are taken by the whole wave
-			const int n_coop = n_big < coop ? n_big : coop;
-			for (int w = 0; w < n_coop; ++w) {
-				const SeedRange rg = cur[w];
-				for (int d = lane; d < 256; d += 64) hist[w * 256 + d] = 0;
-				__syncthreads();
-				for (int q = rg.beg + lane; q < rg.end; q += 64) atomicAdd(&hist[w * 256 + (int)(key[q] >> rg.shift & 0xff)], 1u);
+			for (int w = lane; w < n_small; w += SEED_TPB) {                         // ksort.h:148, a thread per small range
+				const SeedRange rg = cur[q_big + w];
+				seed_isort(key, idx, rg.beg, rg.end);
 			}
-			__syncthreads();
-			if (lane < workers) {
-				for (int w = lane; w < n_big + n_small; w += workers) {
-					const SeedRange rg = w < n_big ? cur[w] : cur[SEED_QBIG + (w - n_big)];
-					const int rb = rg.beg, re = rg.end, len = re - rb, sh = rg.shift;
-					if (len <= 64) { seed_isort(key, idx, rb, re); continue; }           // ksort.h:143,148
-					if (w < n_coop) for (int d = 0; d < 256; ++d) tail[d] = (uint16_t)hist[w * 256 + d];
-					else {
-						for (int d = 0; d < 256; ++d) tail[d] = 0;
-						for (int q = rb; q < re; ++q) ++tail[key[q] >> sh & 0xff];       // ksort.h:126
-					}
-					const int d0 = (int)(key[rb] >> sh & 0xff);
-					if (tail[d0] == len) {                                               // one bucket: the pass moves nothing
-						if (sh) nxt[atomicAdd(&ncnt[0], 1)] = SeedRange{(uint16_t)rb, (uint16_t)re, (uint16_t)(sh > 8 ? sh - 8 : 0), 0};
-						continue;
-					}
-					int acc = rb;
-					for (int d = 0; d < 256; ++d) { head[d] = (uint16_t)acc; acc += tail[d]; tail[d] = (uint16_t)acc; }
-					for (int d = 0; d < 256;) {                                          // ksort.h:129-141, cycle-leader permutation
-						if (head[d] != tail[d]) {
-							int l = (int)(key[head[d]] >> sh & 0xff);
+			for (int w = wave; w < n_big; w += SEED_TPB / 64) {                      // a wave per large range
+				const SeedRange rg = cur[w];
+				const int rb = rg.beg, re = rg.end, len = re - rb, sh = rg.shift, next = sh > 8 ? sh - 8 : 0;
+				if (len <= 64) { if (wl == 0) seed_isort(key, idx, rb, re); continue; }       // ksort.h:143 (a whole read of <= 64 anchors)
+				for (int d = wl; d < 256; d += 64) cnt[d] = 0;
+				wave_global_fence();
+				for (int q = rb + wl; q < re; q += 64) {                             // ksort.h:126, and the digits written down
+					const int dg = (int)(key[q] >> sh & 0xff);
+					lab[q] = (uint8_t)dg;
+					atomicAdd(&cnt[dg], 1u);
+				}
+				wave_global_fence();
+				if ((int)cnt[(int)(key[rb] >> sh & 0xff)] == len) {                   // one bucket: the pass moves nothing
+					if (wl == 0 && sh) nxt[atomicAdd(&ncnt[0], 1)] = SeedRange{(uint16_t)rb, (uint16_t)re, (uint16_t)next, 0};
+					wave_global_fence();
+					continue;
+				}
+				{                                                                    // ksort.h:127-128: lane wl owns digits 4 wl .. 4 wl + 3
+					const int c0 = (int)cnt[4 * wl], c1 = (int)cnt[4 * wl + 1], c2 = (int)cnt[4 * wl + 2], c3 = (int)cnt[4 * wl + 3];
+					int incl = c0 + c1 + c2 + c3;
+					for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (wl >= d) incl += t; }
+					int acc = rb + incl - (c0 + c1 + c2 + c3);
+					head[4 * wl] = start[4 * wl] = (uint16_t)acc; acc += c0; tail[4 * wl] = (uint16_t)acc;
+					head[4 * wl + 1] = start[4 * wl + 1] = (uint16_t)acc; acc += c1; tail[4 * wl + 1] = (uint16_t)acc;
+					head[4 * wl + 2] = start[4 * wl + 2] = (uint16_t)acc; acc += c2; tail[4 * wl + 2] = (uint16_t)acc;
+					head[4 * wl + 3] = start[4 * wl + 3] = (uint16_t)acc; acc += c3; tail[4 * wl + 3] = (uint16_t)acc;
+				}
+				wave_global_fence();
+				// ksort.h:129-141.  The loop reads every element once, at a bucket's head, before anything was stored there: its
+				// course depends on the digits at the original places only (see k_seed_sort_huge).  One lane replays it over the
+				// digit bytes and notes the source of every position (in the read's output range, free until the final gather);
+				// the wave then moves keys and indices.
+				if (wl == 0) {
+					for (int d = 0; d < 256; ++d) {
+						int hd = head[d];
+						const int td = tail[d];
+						while (hd != td) {
+							int l = lab[hd];
 							if (l != d) {
-								uint64_t ck = key[head[d]], sk; uint16_t ci = idx[head[d]], si;
+								int carry = hd;
 								do {
-									sk = ck; si = ci;
 									const int hp = head[l];
-									ck = key[hp]; ci = idx[hp];
-									key[hp] = sk; idx[hp] = si;
+									ag[hp].y = (uint64_t)carry;
+									carry = hp;
 									head[l] = (uint16_t)(hp + 1);
-									l = (int)(ck >> sh & 0xff);
+									l = lab[hp];
 								} while (l != d);
-								const int hp = head[d];
-								key[hp] = ck; idx[hp] = ci;
-								head[d] = (uint16_t)(hp + 1);
-							} else ++head[d];
-						} else ++d;
-					}
-					if (sh) {                                                            // ksort.h:143-149: sub-ranges become work items
-						const int next = sh > 8 ? sh - 8 : 0;
-						int sb = rb;
-						for (int d = 0; d < 256; ++d) {
-							const int se = tail[d];
-							if (se - sb > 64) nxt[atomicAdd(&ncnt[0], 1)] = SeedRange{(uint16_t)sb, (uint16_t)se, (uint16_t)next, 0};
-							else if (se - sb > 1) {
-								const int k = atomicAdd(&ncnt[1], 1);
-								if (k < SEED_Q - SEED_QBIG) nxt[SEED_QBIG + k] = SeedRange{(uint16_t)sb, (uint16_t)se, (uint16_t)next, 0};
-								else seed_isort(key, idx, sb, se);
-							}
-							sb = se;
+								ag[hd].y = (uint64_t)carry;
+							} else ag[hd].y = (uint64_t)hd;
+							++hd;
 						}
 					}
 				}
+				wave_global_fence();
+				for (int q = rb + wl; q < re; q += 64) {
+					const int p = (int)ag[q].y;
+					ulonglong2 t; t.x = key[p]; t.y = idx[p];
+					ag[q] = t;
+				}
+				wave_global_fence();
+				for (int q = rb + wl; q < re; q += 64) { const ulonglong2 t = ag[q]; key[q] = t.x; idx[q] = (uint16_t)t.y; }
+				wave_global_fence();
+				if (sh) {                                                            // ksort.h:143-149: the buckets are the next round's work
+					for (int d = 4 * wl; d < 4 * wl + 4; ++d) {
+						const int sb = start[d], se = tail[d];
+						if (se - sb > 64) nxt[atomicAdd(&ncnt[0], 1)] = SeedRange{(uint16_t)sb, (uint16_t)se, (uint16_t)next, 0};
+						else if (se - sb > 1) {
+							const int k = atomicAdd(&ncnt[1], 1);
+							if (k < q_slots - q_big) nxt[q_big + k] = SeedRange{(uint16_t)sb, (uint16_t)se, (uint16_t)next, 0};
+							else seed_isort(key, idx, sb, se);
+						}
+					}
+				}
+				wave_global_fence();
 			}
 			__syncthreads();
 			if (lane == 0) { qn[2 * which] = 0; qn[2 * which + 1] = 0; }
 			__syncthreads();
 		}
-		for (int i = lane; i < n; i += 64) a[b + i] = src[b + idx[i]];
+		for (int i = lane; i < n; i += SEED_TPB) a[b + i] = src[b + idx[i]];
 	}
 }
 
 size_t seed_sort_lds_bytes(int max_n, int workers, int coop)
 {
-	return (((size_t)max_n * 10 + 7) & ~(size_t)7) + (size_t)workers * 512 * 2 + 2 * (size_t)SEED_Q * sizeof(SeedRange) + 16 + (size_t)coop * 1024;
+	(void)coop;
+	return (((size_t)max_n * 10 + 7) & ~(size_t)7) + (size_t)(SEED_TPB / 64) * (768 * 2 + 256 * 4)
+	       + 2 * (size_t)(seed_big_slots(max_n) + seed_small_slots(workers)) * sizeof(SeedRange) + 16 + (((size_t)max_n + 7) & ~(size_t)7);
 }
 
 hipError_t launch_seed_collect(hipStream_t st, const SeedIndex &ix, int flag, int max_occ, int64_t n_reads, int64_t n_mini,
@@ -588,7 +622,7 @@ hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag
 		if (cap > 0) {
 			size_t lds = seed_sort_lds_bytes(max_n, 32, 8);
 			if (max_n2 > max_n && seed_sort_lds_bytes(max_n2, 4, 2) > lds) lds = seed_sort_lds_bytes(max_n2, 4, 2);
-			hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(64), lds, st, n_reads, max_n, max_n2, try_network, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a, items, n_items);
+			hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(SEED_TPB), lds, st, n_reads, max_n, max_n2, try_network, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a, items, n_items);
 		}
 		// reads beyond SEED_HUGE_STACK x cap anchors: one thread each in global memory
 		hipLaunchKernelGGL(k_seed_sort_big, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, st, n_reads, huge_max, d_off, (const ulonglong2*)d_unsorted,

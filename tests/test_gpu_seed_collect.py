@@ -85,7 +85,7 @@ def test_gpu_seed_collection_at_scale():
         assert np.array_equal(rep_len, g["rep_len"]) and np.array_equal(mp, g["mini_pos"])
 
 
-def _build_image(rng, n_keys, max_cnt, b_bits=6):
+def _build_image(rng, n_keys, max_cnt, b_bits=6, rid_pool=None):
     """A synthetic index image in the reference's FPGA layout (index.c:603-720): random minimizers with 1..max_cnt positions,
     hashed into 2^b_bits buckets with khash's own probing (khash.h:218-231).  Returns (blobs, minimizer values)."""
     keys = rng.choice(1 << 34, size=n_keys, replace=False).astype(np.uint64) + np.uint64(1)
@@ -104,7 +104,7 @@ def _build_image(rng, n_keys, max_cnt, b_bits=6):
         slots_k, slots_v, used, p_local = [0] * nb, [0] * nb, [False] * nb, []
         for m in bk:
             cnt = int(rng.integers(1, max_cnt + 1))
-            pos = [int(rng.integers(0, 1 << 20)) << 43 | int(rng.integers(0, 1 << 21)) << 22 | int(rng.integers(0, 2)) << 21 | int(rng.integers(0, 1 << 10))
+            pos = [int(rng.integers(0, rid_pool or 1 << 20)) << 43 | int(rng.integers(0, 1 << 21)) << 22 | int(rng.integers(0, 2)) << 21 | int(rng.integers(0, 1 << 10))
                    for _ in range(cnt)]
             key = (m >> b_bits) << 1
             i, step = (key >> 1) & (nb - 1), 0
@@ -137,10 +137,10 @@ def _build_image(rng, n_keys, max_cnt, b_bits=6):
     return blobs, keys
 
 
-def _synthetic_case(seed, max_cnt, n_mini, rep_pct):
+def _synthetic_case(seed, max_cnt, n_mini, rep_pct, rid_pool=None):
     from minimap2_chaindp_amd import fpga
     rng = np.random.default_rng(seed)
-    blobs, keys = _build_image(rng, 3000, max_cnt)
+    blobs, keys = _build_image(rng, 3000, max_cnt, rid_pool=rid_pool)
     n_reads, flag, max_occ = 6, int(rng.choice([0, 3, 0x100000])), int(max_cnt * 3 // 4 + 2)
     mini, mini_off, bid, qlen = [], [0], [], []
     for r in range(n_reads):
@@ -185,6 +185,13 @@ def test_gpu_seed_collection_against_host_statement_on_synthetic_images(seed, ma
     memory).  Expected values come from the host statement (csrc/seed_collect.cpp), itself pinned against the reference
     on the CPU tier."""
     _synthetic_case(seed, max_cnt, n_mini, rep_pct)
+
+
+@pytest.mark.parametrize("seed,n_mini,rid_pool", [(8, 1050, 160), (9, 1100, 90), (10, 700, 60)])
+def test_gpu_seed_collection_with_few_targets(seed, n_mini, rid_pool):
+    """Reads of 8-13 k anchors on a few dozen targets: in the middle levels of the sort more than a hundred buckets of more
+    than 64 anchors are pending at a time (the large-range slots of the LDS queues), with ties throughout."""
+    _synthetic_case(seed, 40, n_mini, 30, rid_pool=rid_pool)
 
 
 @pytest.mark.parametrize("limits,lab_cap", [("256,512", "1024"), ("128,128", "100000"), ("1024,4096", "4096")])

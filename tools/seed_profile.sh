@@ -16,3 +16,9 @@ PY
 }
 run default X=1
 run exact CHAINDP_SEED_FORCE_EXACT=1
+if [ "${1:-}" = "limits" ]; then
+run m8192 CHAINDP_SEED_MAX_N=8192,8192
+run m8192_exact CHAINDP_SEED_MAX_N=8192,8192 CHAINDP_SEED_FORCE_EXACT=1
+run m4096 CHAINDP_SEED_MAX_N=4096,4096
+run m4096_exact CHAINDP_SEED_MAX_N=4096,4096 CHAINDP_SEED_FORCE_EXACT=1
+fi
