@@ -737,7 +737,7 @@ static int collect_seeds_impl(chaindp_ctx *ctx, const chaindp_index_t *ix, int f
 		if (m < 64) m = 64;
 		if (cap < 256) cap = 256;
 		while (m > 0 && chaindp::seed_sort_lds_bytes(m, 32, 8) > (size_t)lds_limit) m -= 512;
-		while (m2 > m && chaindp::seed_sort_lds_bytes(m2, 4, 2) > (size_t)lds_limit) m2 -= 512;
+		while (m2 > m && chaindp::seed_sort_lds_bytes(m2, 4, 2) > (size_t)lds_limit) m2 -= 64;
 		ctx->seed_lab_cap = cap;
 		ctx->seed_max_n = m; ctx->seed_max_n2 = m2;
 	}

@@ -368,16 +368,17 @@ __global__ __launch_bounds__(256) void k_seed_sort_huge(int64_t n_reads, int min
 	}
 }
 
-// radix_sort_128x (ksort.h:101-151) of one read by one wave, in LDS, on (key, original index) pairs.  The reference's
-// in-place bucket permutation is sequential by nature (its order of equal keys depends on every swap before), so each
-// bucket range is still permuted by ONE lane, step by step as the reference does -- but disjoint ranges are
-// independent, so after the first one or two levels up to 32 lanes work on as many ranges at a time, the histograms and bucket
-// pointers live in LDS (16-bit: a read here has at most max_n <= 65535 anchors), and a level on which every key of
-// the range has the same digit is skipped (the reference's pass over it moves nothing).
-// LDS: keys[max_n] u64 | idx[max_n] u16 | workers x (head[256], tail[256]) u16 | two queues of ranges | counters and flags |
-// coop x 256 digit counts | digits[max_n] u8
-// (32 workers for reads of up to 8192 anchors, 4 workers for reads of up to ~13 k; chosen per read inside one launch).
-// A queue keeps its first max_n / 65 + 2 slots for ranges of more than 64 anchors (they are disjoint, so they always fit);
+// radix_sort_128x (ksort.h:101-151) of one read (or one bucket handed over by k_seed_sort_huge) by one workgroup of four
+// waves, in LDS, on (key, original index) pairs.  A read whose keys all differ -- almost every read -- has a unique
+// sorted order and is done by a bitonic network.  Otherwise the reference's procedure is followed level by level:
+// ranges of more than 64 anchors go to the waves one at a time (digit counts by the wave, the bucket permutation
+// replayed over the digits by one lane, keys and indices moved by the wave), ranges of up to 64 are insertion-sorted
+// one per thread, and a level on which every key of a range has the same digit is skipped (the reference's pass
+// over it moves nothing).  Positions are 16-bit: a read here has at most max_n2 <= 65535 anchors.
+// LDS: keys[n] u64 | idx[n] u16 | 4 x (head, tail, start)[256] u16 | 4 x counts[256] u32 | two queues of ranges |
+// 4 counters | digits[n] u8, with n = max_n (<= 8192, 1024 queue slots for small ranges) or max_n2 (~13 k, 256 slots),
+// chosen per read inside one launch.
+// A queue keeps its first n / 65 + 2 slots for ranges of more than 64 anchors (they are disjoint, so they always fit);
 // small ranges that find the rest full are insertion-sorted on the spot by the lane that made them.
 struct SeedRange { uint16_t beg, end; uint16_t shift, pad; };
 __host__ __device__ inline int seed_big_slots(int max_n) { return max_n / 65 + 2; }                    // queue slots for ranges of > 64 anchors: they are disjoint
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 		__syncthreads();
 		// A sorted order is unique when all keys differ, and then any sort will do: try a bitonic network first (the whole
 		// workgroup busy) and keep its result unless two neighbours are equal; only reads with equal x go through the
-		// reference's procedure below (whose serial top levels take milliseconds).
+		// reference's procedure below (whose top levels are serial walks over thousands of digits).
 		int pow2 = 64;
 		while (pow2 < n) pow2 <<= 1;
 		if (try_network) {
