@@ -504,6 +504,7 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 					wave_global_fence();
 					continue;
 				}
+				int n_digits, d_lo, d_hi;                                            // digits in use; the lowest and the highest of them
 				{                                                                    // ksort.h:127-128: lane wl owns digits 4 wl .. 4 wl + 3
 					const int c0 = (int)cnt[4 * wl], c1 = (int)cnt[4 * wl + 1], c2 = (int)cnt[4 * wl + 2], c3 = (int)cnt[4 * wl + 3];
 					int incl = c0 + c1 + c2 + c3;
@@ -513,13 +514,68 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 					head[4 * wl + 1] = start[4 * wl + 1] = (uint16_t)acc; acc += c1; tail[4 * wl + 1] = (uint16_t)acc;
 					head[4 * wl + 2] = start[4 * wl + 2] = (uint16_t)acc; acc += c2; tail[4 * wl + 2] = (uint16_t)acc;
 					head[4 * wl + 3] = start[4 * wl + 3] = (uint16_t)acc; acc += c3; tail[4 * wl + 3] = (uint16_t)acc;
+					n_digits = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+					d_lo = c0 ? 4 * wl : c1 ? 4 * wl + 1 : c2 ? 4 * wl + 2 : c3 ? 4 * wl + 3 : 256;
+					d_hi = c3 ? 4 * wl + 3 : c2 ? 4 * wl + 2 : c1 ? 4 * wl + 1 : c0 ? 4 * wl : -1;
+					for (int d = 32; d > 0; d >>= 1) {
+						n_digits += __shfl_xor(n_digits, d);
+						d_lo = min(d_lo, __shfl_xor(d_lo, d)); d_hi = max(d_hi, __shfl_xor(d_hi, d));
+					}
 				}
 				wave_global_fence();
 				// ksort.h:129-141.  The loop reads every element once, at a bucket's head, before anything was stored there: its
 				// course depends on the digits at the original places only (see k_seed_sort_huge).  One lane replays it over the
 				// digit bytes and notes the source of every position (in the read's output range, free until the final gather);
 				// the wave then moves keys and indices.
-				if (wl == 0) {
+				if (n_digits == 2) {
+					// Two buckets, A = [rb, mid) for d_lo and B = [mid, re) for d_hi (the strand level always; often the next one):
+					// the loop has a closed form.  With a_1 < a_2 < .. the places in A that hold a B element and b_1 < b_2 < ..
+					// the places in B that hold an A element, cycle j carries a_j to the head of B, which stands just behind
+					// b_(j-1); every B element from there on moves up one place until b_j is reached, whose A element closes
+					// the cycle at a_j.  So a_j receives b_j; in B a place q <= b_m receives a_j if it starts segment j
+					// (q = mid or q - 1 holds an A element) and q - 1 otherwise; everything else stays.  Lists in the .x fields.
+					const int mid = tail[d_lo];
+					const unsigned long long below = (1ull << wl) - 1;
+					int run = 0;
+					for (int base = rb; base < mid; base += 64) {
+						const int q = base + wl;
+						const bool f = q < mid && lab[q] == d_hi;
+						const unsigned long long m = __ballot(f);
+						if (f) ag[rb + run + __popcll(m & below)].x = (uint64_t)q;
+						run += __popcll(m);
+					}
+					const int n_cycles = run;
+					run = 0;
+					for (int base = mid; base < re; base += 64) {
+						const int q = base + wl;
+						const bool f = q < re && lab[q] == d_lo;
+						const unsigned long long m = __ballot(f);
+						if (f) ag[mid + run + __popcll(m & below)].x = (uint64_t)q;
+						run += __popcll(m);
+					}
+					wave_global_fence();
+					run = 0;
+					for (int base = rb; base < mid; base += 64) {
+						const int q = base + wl;
+						const bool f = q < mid && lab[q] == d_hi;
+						const unsigned long long m = __ballot(f);
+						if (q < mid) ag[q].y = f ? ag[mid + run + __popcll(m & below)].x : (uint64_t)q;
+						run += __popcll(m);
+					}
+					run = 0;
+					for (int base = mid; base < re; base += 64) {
+						const int q = base + wl;
+						const bool f = q < re && lab[q] == d_lo;
+						const unsigned long long m = __ballot(f);
+						const int before = run + __popcll(m & below);                 // A elements in [mid, q)
+						if (q < re) {
+							uint64_t from = (uint64_t)q;
+							if (before < n_cycles) from = (q == mid || lab[q - 1] == d_lo) ? ag[rb + before].x : (uint64_t)(q - 1);
+							ag[q].y = from;
+						}
+						run += __popcll(m);
+					}
+				} else if (wl == 0) {
 					for (int d = 0; d < 256; ++d) {
 						int hd = head[d];
 						const int td = tail[d];
