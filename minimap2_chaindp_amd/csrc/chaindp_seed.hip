@@ -335,8 +335,60 @@ __global__ __launch_bounds__(256) void k_seed_sort_huge(int64_t n_reads, int min
 				continue;
 			}
 			if (tid == 0) {
-				int acc = rb;
-				for (int d = 0; d < 256; ++d) { head[d] = acc; start[d] = acc; acc += (int)hist[d]; tail[d] = acc; }
+				int acc = rb, n_digits = 0, d_lo = 256, d_hi = -1;
+				for (int d = 0; d < 256; ++d) {
+					head[d] = acc; start[d] = acc; acc += (int)hist[d]; tail[d] = acc;
+					if (hist[d]) { ++n_digits; if (d_lo == 256) d_lo = d; d_hi = d; }
+				}
+				sp[1] = n_digits; sp[2] = d_lo; sp[3] = d_hi;
+			}
+			__syncthreads();
+			if (sp[1] == 2 && !global_digits) {
+				// two buckets (the strand level): closed form, see k_seed_sort; lists in the .y fields, by the first wave
+				if (tid < 64) {
+					const int d_lo = sp[2], d_hi = sp[3], mid = tail[d_lo];
+					const unsigned long long below = (1ull << tid) - 1;
+					int run = 0;
+					for (int base = rb; base < mid; base += 64) {
+						const int q = base + tid;
+						const bool f = q < mid && lab[q - rb] == d_hi;
+						const unsigned long long m = __ballot(f);
+						if (f) ar[rb + run + __popcll(m & below)].y = (uint64_t)q;
+						run += __popcll(m);
+					}
+					const int n_cycles = run;
+					run = 0;
+					for (int base = mid; base < re; base += 64) {
+						const int q = base + tid;
+						const bool f = q < re && lab[q - rb] == d_lo;
+						const unsigned long long m = __ballot(f);
+						if (f) ar[mid + run + __popcll(m & below)].y = (uint64_t)q;
+						run += __popcll(m);
+					}
+					wave_global_fence();
+					run = 0;
+					for (int base = rb; base < mid; base += 64) {
+						const int q = base + tid;
+						const bool f = q < mid && lab[q - rb] == d_hi;
+						const unsigned long long m = __ballot(f);
+						if (q < mid) ar[q].x = f ? ar[mid + run + __popcll(m & below)].y : (uint64_t)q;
+						run += __popcll(m);
+					}
+					run = 0;
+					for (int base = mid; base < re; base += 64) {
+						const int q = base + tid;
+						const bool f = q < re && lab[q - rb] == d_lo;
+						const unsigned long long m = __ballot(f);
+						const int before = run + __popcll(m & below);
+						if (q < re) {
+							uint64_t from = (uint64_t)q;
+							if (before < n_cycles) from = (q == mid || lab[q - 1 - rb] == d_lo) ? ar[rb + before].y : (uint64_t)(q - 1);
+							ar[q].x = from;
+						}
+						run += __popcll(m);
+					}
+				}
+			} else if (tid == 0) {
 				if (global_digits) seed_huge_walk<true>(lab, head, tail, ar, rb);
 				else seed_huge_walk<false>(lab, head, tail, ar, rb);
 			}
