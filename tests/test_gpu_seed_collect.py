@@ -85,7 +85,7 @@ def test_gpu_seed_collection_at_scale():
         assert np.array_equal(rep_len, g["rep_len"]) and np.array_equal(mp, g["mini_pos"])
 
 
-def _build_image(rng, n_keys, max_cnt, b_bits=6, rid_pool=None):
+def _build_image(rng, n_keys, max_cnt, b_bits=6, rid_pool=None, pos_bits=21):
     """A synthetic index image in the reference's FPGA layout (index.c:603-720): random minimizers with 1..max_cnt positions,
     hashed into 2^b_bits buckets with khash's own probing (khash.h:218-231).  Returns (blobs, minimizer values)."""
     keys = rng.choice(1 << 34, size=n_keys, replace=False).astype(np.uint64) + np.uint64(1)
@@ -104,7 +104,7 @@ def _build_image(rng, n_keys, max_cnt, b_bits=6, rid_pool=None):
         slots_k, slots_v, used, p_local = [0] * nb, [0] * nb, [False] * nb, []
         for m in bk:
             cnt = int(rng.integers(1, max_cnt + 1))
-            pos = [int(rng.integers(0, rid_pool or 1 << 20)) << 43 | int(rng.integers(0, 1 << 21)) << 22 | int(rng.integers(0, 2)) << 21 | int(rng.integers(0, 1 << 10))
+            pos = [int(rng.integers(0, rid_pool or 1 << 20)) << 43 | int(rng.integers(0, 1 << pos_bits)) << 22 | int(rng.integers(0, 2)) << 21 | int(rng.integers(0, 1 << 10))
                    for _ in range(cnt)]
             key = (m >> b_bits) << 1
             i, step = (key >> 1) & (nb - 1), 0
@@ -137,10 +137,10 @@ def _build_image(rng, n_keys, max_cnt, b_bits=6, rid_pool=None):
     return blobs, keys
 
 
-def _synthetic_case(seed, max_cnt, n_mini, rep_pct, rid_pool=None):
+def _synthetic_case(seed, max_cnt, n_mini, rep_pct, rid_pool=None, pos_bits=21, quiet=False):
     from minimap2_chaindp_amd import fpga
     rng = np.random.default_rng(seed)
-    blobs, keys = _build_image(rng, 3000, max_cnt, rid_pool=rid_pool)
+    blobs, keys = _build_image(rng, 3000, max_cnt, rid_pool=rid_pool, pos_bits=pos_bits)
     n_reads, flag, max_occ = 6, int(rng.choice([0, 3, 0x100000])), int(max_cnt * 3 // 4 + 2)
     mini, mini_off, bid, qlen = [], [0], [], []
     for r in range(n_reads):
@@ -173,7 +173,9 @@ def _synthetic_case(seed, max_cnt, n_mini, rep_pct, rid_pool=None):
         assert np.array_equal(a[off[r]:off[r + 1]], exp[r][0]), (seed, r, sizes[r], "anchors")
         assert rep_len[r] == exp[r][1] and np.array_equal(mp[mpo[r]:mpo[r + 1]], exp[r][2]), (seed, r)
     ties = sum(int((np.diff(e[0][:, 0]) == 0).sum()) for e in exp if len(e[0]) > 1)
-    print(f"\nseed {seed}: anchors per read {sizes}, equal-x pairs {ties}, {dt * 1e3:.1f} ms with transfers")
+    if not quiet:
+        print(f"\nseed {seed}: anchors per read {sizes}, equal-x pairs {ties}, {dt * 1e3:.1f} ms with transfers")
+    return sizes, ties
 
 
 @pytest.mark.parametrize("seed,max_cnt,n_mini,rep_pct", [(1, 3, 400, 0), (2, 6, 900, 20), (3, 40, 500, 30), (4, 12, 2500, 40), (5, 90, 400, 25), (6, 90, 1500, 35),
@@ -192,6 +194,23 @@ def test_gpu_seed_collection_with_few_targets(seed, n_mini, rid_pool):
     """Reads of 8-13 k anchors on a few dozen targets: in the middle levels of the sort more than a hundred buckets of more
     than 64 anchors are pending at a time (the large-range slots of the LDS queues), with ties throughout."""
     _synthetic_case(seed, 40, n_mini, 30, rid_pool=rid_pool)
+
+
+def test_gpu_seed_collection_fuzz():
+    """Random shapes of the sort's input: one target to a million (how many buckets a level has), reference positions
+    confined to 4..21 bits (on which levels equal keys separate, if at all), few to many hits per minimizer, reads of a
+    few hundred to ~20 k anchors.  CHAINDP_FUZZ_SCALE multiplies the number of cases."""
+    n_cases = 24 * max(1, int(os.environ.get("CHAINDP_FUZZ_SCALE", "1")))
+    rng = np.random.default_rng(20260104)
+    seen = []
+    for c in range(n_cases):
+        rid_pool = int(rng.choice([1, 2, 3, 7, 40, 150, 300, 700, 70000, 1 << 20]))
+        pos_bits = int(rng.choice([4, 8, 9, 13, 17, 21]))
+        max_cnt = int(rng.choice([3, 10, 40, 90]))
+        n_mini = int(rng.choice([200, 600, 1500])) * (1 if max_cnt > 10 else 4)
+        sizes, ties = _synthetic_case(1000 + c, max_cnt, n_mini, int(rng.choice([0, 20, 45])), rid_pool=rid_pool, pos_bits=pos_bits, quiet=True)
+        seen.append((max(sizes), ties))
+    print(f"\n{n_cases} cases; largest read {max(s for s, _ in seen)} anchors; cases with ties {sum(1 for _, t in seen if t)}")
 
 
 @pytest.mark.parametrize("limits,lab_cap", [("256,512", "1024"), ("128,128", "100000"), ("1024,4096", "4096")])
