@@ -7,6 +7,7 @@
  * cites the reference lines whose arithmetic it must reproduce bit for bit.
  */
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include <pthread.h>
 #include <time.h>
@@ -403,4 +404,125 @@ double co_time_top(const co_params_t *par, int64_t n_reads, const int64_t *off,
 	if (checksum) *checksum = h;
 	free(th); free(jobs); free(cut);
 	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* ---- hit.c:8-95 ------------------------------------------------------------ */
+
+static uint64_t co_hash64(uint64_t key)                      /* hit.c:40-50 */
+{
+	key = (~key + (key << 21));
+	key = key ^ key >> 24;
+	key = ((key + (key << 3)) + (key << 8));
+	key = key ^ key >> 14;
+	key = ((key + (key << 2)) + (key << 4));
+	key = key ^ key >> 28;
+	key = (key + (key << 31));
+	return key;
+}
+
+static void co_reg_set_coor(co_reg_t *r, int32_t qlen, const co_anchor_t *a)   /* hit.c:8-38 */
+{
+	const int32_t k = r->as, last = r->as + r->cnt - 1, q_span = (int32_t)(a[k].y >> 32 & 0xff);
+	int32_t i;
+	const int rev = (int)(a[k].x >> 63);
+	r->bits = (r->bits & ~(1u << CO_REG_REV_BIT)) | (uint32_t)rev << CO_REG_REV_BIT;
+	r->rid = (int32_t)(a[k].x << 1 >> 33);
+	r->rs = (int32_t)a[k].x + 1 > q_span ? (int32_t)a[k].x + 1 - q_span : 0;
+	r->re = (int32_t)a[last].x + 1;
+	if (!rev) {
+		r->qs = (int32_t)a[k].y + 1 - q_span;
+		r->qe = (int32_t)a[last].y + 1;
+	} else {
+		r->qs = qlen - ((int32_t)a[last].y + 1);
+		r->qe = qlen - ((int32_t)a[k].y + 1 - q_span);
+	}
+	r->mlen = r->blen = 0;
+	if (r->cnt <= 0) return;
+	r->mlen = r->blen = q_span;
+	for (i = k + 1; i <= last; ++i) {
+		const int32_t span = (int32_t)(a[i].y >> 32 & 0xff);
+		const int32_t tl = (int32_t)a[i].x - (int32_t)a[i - 1].x;
+		const int32_t ql = (int32_t)a[i].y - (int32_t)a[i - 1].y;
+		r->blen += tl > ql ? tl : ql;
+		r->mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
+	}
+}
+
+void co_gen_regs(uint32_t hash, int32_t qlen, int32_t n_u, const uint64_t *u, const co_anchor_t *a, co_reg_t *out)
+{
+	co_anchor_t *z, tmp;
+	int32_t i, k;
+	if (n_u <= 0) return;
+	z = (co_anchor_t*)malloc((size_t)n_u * sizeof(co_anchor_t));
+	for (i = k = 0; i < n_u; ++i) {                          /* hit.c:61-68: key = score and count, low bits scrambled */
+		const uint32_t h = (uint32_t)co_hash64((co_hash64(a[k].x) + co_hash64(a[k].y)) ^ hash);
+		z[i].x = u[i] ^ h;
+		z[i].y = (uint64_t)k << 32 | (uint32_t)(int32_t)u[i];
+		k += (int32_t)u[i];
+	}
+	co_radix_sort_128x(z, z + n_u);
+	for (i = 0; i < n_u >> 1; ++i) tmp = z[i], z[i] = z[n_u - 1 - i], z[n_u - 1 - i] = tmp;   /* larger score first */
+	memset(out, 0, (size_t)n_u * sizeof(co_reg_t));
+	for (i = 0; i < n_u; ++i) {                              /* hit.c:74-86 */
+		co_reg_t *r = &out[i];
+		r->id = i;
+		r->parent = -1;                                      /* MM_PARENT_UNSET, mmpriv.h */
+		r->score = r->score0 = (int32_t)(z[i].x >> 32);
+		r->hash = (uint32_t)z[i].x;
+		r->cnt = (int32_t)z[i].y;
+		r->as = (int32_t)(z[i].y >> 32);
+		r->div = -1.0f;
+		co_reg_set_coor(r, qlen, a);
+	}
+	free(z);
+}
+
+/* ---- esterr.c:7-64 ---------------------------------------------------------- */
+
+static int32_t co_for_qpos(int32_t qlen, const co_anchor_t *a)      /* esterr.c:7-14 */
+{
+	int32_t x = (int32_t)a->y;
+	const int32_t q_span = (int32_t)(a->y >> 32 & 0xff);
+	if (a->x >> 63) x = qlen - 1 - (x + 1 - q_span);
+	return x;
+}
+
+void co_est_err(const int32_t *ref_len, int32_t qlen, int32_t n_regs, co_reg_t *regs, const co_anchor_t *a,
+                int32_t n, const uint64_t *mini_pos, int32_t *n_match_out, int32_t *n_tot_out)
+{
+	int32_t i;
+	uint64_t sum_k = 0;
+	float avg_k;
+	if (n == 0) return;
+	for (i = 0; i < n; ++i) sum_k += mini_pos[i] >> 32 & 0xff;
+	avg_k = (float)sum_k / n;
+	for (i = 0; i < n_regs; ++i) {
+		co_reg_t *r = &regs[i];
+		const int rev = (int)(r->bits >> CO_REG_REV_BIT & 1);
+		int32_t st, en, j, k, n_match, n_tot, x, L = 0, R = n - 1;
+		r->div = -1.0f;
+		if (n_match_out) n_match_out[i] = 0;
+		if (n_tot_out) n_tot_out[i] = 0;
+		if (r->cnt == 0) continue;
+		x = co_for_qpos(qlen, rev ? &a[r->as + r->cnt - 1] : &a[r->as]);
+		st = -1;
+		while (L <= R) {                                     /* esterr.c:16-28 */
+			const int32_t m = (int32_t)(((uint64_t)L + R) >> 1), y = (int32_t)mini_pos[m];
+			if (y < x) L = m + 1;
+			else if (y > x) R = m - 1;
+			else { st = m; break; }
+		}
+		if (st < 0) continue;
+		en = st;
+		for (k = 1, j = st + 1, n_match = 1; j < n && k < r->cnt; ++j) {
+			x = co_for_qpos(qlen, rev ? &a[r->as + r->cnt - 1 - k] : &a[r->as + k]);
+			if (x == (int32_t)mini_pos[j]) ++k, en = j, ++n_match;
+		}
+		n_tot = en - st + 1;
+		if (r->qs > avg_k && r->rs > avg_k) ++n_tot;
+		if (qlen - r->qs > avg_k && ref_len[r->rid] - r->re > avg_k) ++n_tot;
+		r->div = logf((float)n_tot / n_match) / avg_k;
+		if (n_match_out) n_match_out[i] = n_match;
+		if (n_tot_out) n_tot_out[i] = n_tot;
+	}
 }

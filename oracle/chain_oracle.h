@@ -18,6 +18,8 @@
  *   minimap.h:48-55  mm128_t, struct new_seed
  *   mmpriv.h:21-22   MM_SEED_SEG_SHIFT / MM_SEED_SEG_MASK
  *   ksort.h:101-151  radix_sort_128x / radix_sort_64 (unstable, order matters)
+ *   hit.c:8-95       mm_cal_fuzzy_len, mm_reg_set_coor, hash64, mm_gen_regs (chains -> hits)
+ *   esterr.c:7-64    get_for_qpos, get_mini_idx, mm_est_err (divergence estimate of a hit)
  */
 #ifndef CHAIN_ORACLE_H
 #define CHAIN_ORACLE_H
@@ -67,6 +69,25 @@ co_anchor_t *co_chain_bottom(int min_cnt, int min_sc, const co_seed_t *s, uint32
  * sort below 65 elements). */
 void co_radix_sort_128x(co_anchor_t *beg, co_anchor_t *end);
 void co_radix_sort_64(uint64_t *beg, uint64_t *end);
+
+/* == mm_reg1_t (minimap.h:100-115, 80 B) with two reserved words in the place of its mm_extra_t pointer;
+ * `bits` is the bit-field word (rev = bit 10). */
+typedef struct {
+	int32_t id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0;
+	uint32_t bits, hash;
+	float div;
+	uint32_t reserved[2];
+} co_reg_t;                                                  /* 80 B */
+#define CO_REG_REV_BIT 10
+
+/* hit.c:52-95: the read's chains (u: score<<32|count, a: their anchors, chain after chain) as hits, best score
+ * first; out has room for n_u records.  Fields the reference leaves zero stay zero; parent = -1, div = -1. */
+void co_gen_regs(uint32_t hash, int32_t qlen, int32_t n_u, const uint64_t *u, const co_anchor_t *a, co_reg_t *out);
+
+/* esterr.c:30-64: sets div of every hit from the minimizer positions of the read (mini_pos: q_span<<32 | pos) and
+ * the reference lengths; n_match / n_tot (the integers div is made of) are returned too when the arrays are given. */
+void co_est_err(const int32_t *ref_len, int32_t qlen, int32_t n_regs, co_reg_t *regs, const co_anchor_t *a,
+                int32_t n, const uint64_t *mini_pos, int32_t *n_match, int32_t *n_tot);
 
 /* Batch helpers used by tests and by bench.py's cpu_baseline leg.
  * Reads are given CSR-style: read r owns anchors [off[r], off[r+1]).

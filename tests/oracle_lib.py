@@ -14,6 +14,11 @@ CAP_SO = os.path.join(ROOT, "oracle", "_ref", "libmm2chain_cap.so")
 
 SEED_DTYPE = np.dtype([("x", "<u8"), ("y", "<u8"), ("p", "<i4"), ("f", "<i4")])  # struct new_seed, 24 B
 assert SEED_DTYPE.itemsize == 24
+# mm_reg1_t (minimap.h:100-115), 80 B, with two reserved words where its mm_extra_t pointer is; `bits` is the bit-field word (rev = bit 10)
+REG_DTYPE = np.dtype([(k, "<i4") for k in ("id", "cnt", "rid", "score", "qs", "qe", "rs", "re", "parent", "subsc", "as", "mlen", "blen", "n_sub", "score0")]
+                     + [("bits", "<u4"), ("hash", "<u4"), ("div", "<f4"), ("reserved", "<u4", (2,))])
+assert REG_DTYPE.itemsize == 80
+REF_REG_BYTES = 80            # sizeof(mm_reg1_t) in the reference: 72 B of fields, then the mm_extra_t pointer
 
 
 class CoParams(C.Structure):
@@ -51,6 +56,10 @@ def oracle():
         lib.wm_batch_fpv.argtypes = [P, C.c_int64] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
         lib.co_radix_sort_128x.argtypes = [C.c_void_p, C.c_void_p]
         lib.co_radix_sort_64.argtypes = [C.c_void_p, C.c_void_p]
+        lib.co_gen_regs.restype = None
+        lib.co_gen_regs.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.co_est_err.restype = None
+        lib.co_est_err.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         _oracle = lib
     return _oracle
 
@@ -78,6 +87,10 @@ def ref():
     global _ref
     if _ref is None:
         _ref = C.CDLL(REF_SO)
+        _ref.mm_gen_regs.restype = C.c_void_p
+        _ref.mm_gen_regs.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _ref.mm_est_err.restype = None
+        _ref.mm_est_err.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     return _ref
 
 
@@ -141,6 +154,72 @@ def ref_bottom(min_cnt, min_sc, n_segs, seeds):
     seeds = np.ascontiguousarray(seeds)
     b = ref_cap().mm_chain_dp_bottom(min_cnt, min_sc, n_segs, C.byref(n_u), C.byref(u), None, seeds.ctypes.data, seeds.shape[0])
     return _take_bottom(b, u, n_u.value)
+
+
+# ---- chains -> hits (hit.c:52-95) and their divergence estimate (esterr.c:30-64) ----
+
+def oracle_gen_regs(hash_, qlen, u, b):
+    u = np.ascontiguousarray(u, np.uint64)
+    b = np.ascontiguousarray(b, np.uint64)
+    out = np.zeros(len(u), REG_DTYPE)
+    if len(u):
+        oracle().co_gen_regs(hash_, qlen, len(u), u.ctypes.data, b.ctypes.data, out.ctypes.data)
+    return out
+
+
+def oracle_est_err(ref_len, qlen, regs, b, mini_pos):
+    regs = regs.copy()
+    ref_len = np.ascontiguousarray(ref_len, np.int32)
+    b = np.ascontiguousarray(b, np.uint64)
+    mini_pos = np.ascontiguousarray(mini_pos, np.uint64)
+    n_match, n_tot = np.zeros(max(len(regs), 1), np.int32), np.zeros(max(len(regs), 1), np.int32)
+    oracle().co_est_err(ref_len.ctypes.data, qlen, len(regs), regs.ctypes.data, b.ctypes.data, len(mini_pos), mini_pos.ctypes.data,
+                        n_match.ctypes.data, n_tot.ctypes.data)
+    return regs, n_match[:len(regs)], n_tot[:len(regs)]
+
+
+def _ref_regs_to_np(ptr, n):
+    raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (n * REF_REG_BYTES,)).reshape(n, REF_REG_BYTES)
+    out = np.zeros(n, REG_DTYPE)
+    out.view(np.uint8).reshape(n, 80)[:, :72] = raw[:, :72]
+    return out
+
+
+def ref_gen_regs(hash_, qlen, u, b):
+    """The unmodified reference mm_gen_regs (returns its calloc'd mm_reg1_t[] as REG_DTYPE records)."""
+    u = np.ascontiguousarray(u, np.uint64)
+    b = np.ascontiguousarray(b, np.uint64)
+    if not len(u):
+        return np.zeros(0, REG_DTYPE)
+    ptr = ref().mm_gen_regs(None, hash_, qlen, len(u), u.ctypes.data, b.ctypes.data)
+    out = _ref_regs_to_np(ptr, len(u))
+    _libc.free(ptr)
+    return out
+
+
+class _RefIdxSeq(C.Structure):           # mm_idx_seq_t, minimap.h:58-62
+    _fields_ = [("name", C.c_char_p), ("offset", C.c_uint64), ("len", C.c_uint32)]
+
+
+class _RefIdx(C.Structure):              # the head of mm_idx_t, minimap.h:77-81 (mm_est_err reads seq[rid].len only)
+    _fields_ = [("b", C.c_int32), ("w", C.c_int32), ("k", C.c_int32), ("flag", C.c_int32), ("n_seq", C.c_uint32), ("seq", C.POINTER(_RefIdxSeq))]
+
+
+def ref_est_err(ref_len, qlen, regs, b, mini_pos):
+    """The unmodified reference mm_est_err on mm_reg1_t records rebuilt from `regs`; returns the records with its div."""
+    n = len(regs)
+    raw = np.zeros((n, REF_REG_BYTES), np.uint8)
+    raw[:, :72] = regs.view(np.uint8).reshape(n, 80)[:, :72]
+    seqs = (_RefIdxSeq * max(len(ref_len), 1))()
+    for i, L in enumerate(ref_len):
+        seqs[i].len = int(L)
+    idx = _RefIdx(14, 10, 15, 0, len(ref_len), C.cast(seqs, C.POINTER(_RefIdxSeq)))
+    b = np.ascontiguousarray(b, np.uint64)
+    mini_pos = np.ascontiguousarray(mini_pos, np.uint64)
+    ref().mm_est_err(C.byref(idx), qlen, n, raw.ctypes.data, b.ctypes.data, len(mini_pos), mini_pos.ctypes.data)
+    out = np.zeros(n, REG_DTYPE)
+    out.view(np.uint8).reshape(n, 80)[:, :72] = raw[:, :72]
+    return out
 
 
 # ---- batch calls -------------------------------------------------------------
