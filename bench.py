@@ -200,6 +200,12 @@ def measure_extras(torch, dev, par, off, anchors, total):
         dev.set_profiling(False)
         ex["backtrack"] = {"kernels_ms": kb[0] / max(kb[1], 1), "with_download_s": dt_bt, "chains": int(coff[-1]),
                            "chained_anchors": int(boff[-1]), "anchors_per_s_kernels": total / (kb[0] / max(kb[1], 1) * 1e-3)}
+        # ... and the chains as hits (mm_gen_regs, hit.c:52-95), with the 80 B/hit download
+        n_r = len(off) - 1
+        t0 = time.perf_counter()
+        regs = dev.gen_regs(np.arange(n_r, dtype=np.uint32), np.full(n_r, 1 << 20, np.int32), coff[-1])
+        ex["backtrack"]["gen_regs_with_download_s"] = time.perf_counter() - t0
+        ex["backtrack"]["hits"] = int(len(regs))
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as ol
         k = min(400, len(soff) - 1)

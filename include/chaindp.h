@@ -101,6 +101,34 @@ int chaindp_run_full(chaindp_ctx_t *ctx, const chaindp_params_t *par);
 int chaindp_backtrack(chaindp_ctx_t *ctx, const chaindp_params_t *par, int min_cnt,
                       int64_t *chains_off, uint64_t *u, int64_t *b_off, chaindp_anchor_t *b);
 
+/* ---- chains to hits ----------------------------------------------------------------------
+ * What the reference's host does with a read's chains before alignment: mm_gen_regs (hit.c:52-95, called at
+ * map.c:862) and mm_est_err (esterr.c:30-64, called at map.c:872), over the chains the last chaindp_backtrack left
+ * in HBM.  chaindp_reg_t is mm_reg1_t (minimap.h:100-115, 80 bytes) with two reserved words where its mm_extra_t
+ * pointer is; `bits` is its bit-field word (mapq:8, split:2, rev:1, ... -- rev is bit 10). */
+typedef struct {
+	int32_t id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0;
+	uint32_t bits, hash;
+	float div;
+	uint32_t reserved[2];
+} chaindp_reg_t;
+
+/* mm_gen_regs for every read of the batch: hash[r] and qlen[r] are the call's `hash` and `qlen` arguments for
+ * read r; regs receives chains_off[n_reads] records (the offsets chaindp_backtrack returned), each read's hits in
+ * the reference's order (by score and scrambled count, its unstable radix sort reproduced), `as` relative to the
+ * read's chain anchors, parent = -1, div = -1, everything the reference leaves zero zero.  Bit-exact. */
+int chaindp_gen_regs(chaindp_ctx_t *ctx, const uint32_t *hash, const int32_t *qlen, chaindp_reg_t *regs);
+
+/* mm_est_err for hits the host hands back (after chain_post they may be fewer, split or reordered): read r owns
+ * regs[regs_off[r] .. regs_off[r+1]); only cnt, as, rid, qs, rs, re and the rev bit are read, div is written.
+ * ref_len[rid] is mi->seq[rid].len.  mini_pos_off / mini_pos: the reads' minimizer positions (q_span<<32 | pos,
+ * map.c:141), or both NULL to use the ones chaindp_collect_seeds left resident.  match_tot, if given, receives
+ * n_match and n_tot of esterr.c:53-61 for every hit (0, 0 where div stays -1).  n_match, n_tot and the two float
+ * comparisons are exact; div = logf(n_tot / n_match) / avg_k uses the device's logf, within 2 ulp of the host's. */
+int chaindp_est_err(chaindp_ctx_t *ctx, const int64_t *regs_off, chaindp_reg_t *regs, const int32_t *qlen,
+                    const int32_t *ref_len, int32_t n_ref, const int64_t *mini_pos_off, const uint64_t *mini_pos,
+                    int32_t *match_tot);
+
 /* Scatter/gather variants used by the packet shim, whose reads sit in separate (pinned) packet
  * buffers: upload from one host pointer per read; run the compaction and return only the offsets;
  * then copy each read's new_seed[] straight to its place in a result packet (asynchronous on the

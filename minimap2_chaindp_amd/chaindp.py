@@ -25,7 +25,12 @@ ABI_SYMBOLS = (
     "chaindp_host_free", "chaindp_run_device", "chaindp_set_profiling", "chaindp_get_kernel_ms",
     "chaindp_get_stats", "chaindp_set_ring", "chaindp_run_full", "chaindp_set_variant", "chaindp_upload_gather_ex", "chaindp_scatter_seeds", "chaindp_backtrack",
     "chaindp_index_create", "chaindp_index_destroy", "chaindp_collect_seeds", "chaindp_download_mini_pos", "chaindp_download_anchors", "chaindp_collect_seeds_gather", "chaindp_scatter_mini_pos",
+    "chaindp_gen_regs", "chaindp_est_err",
 )
+
+# chaindp_reg_t == mm_reg1_t (minimap.h:100-115), 80 bytes; `bits` is the bit-field word (rev = bit 10)
+REG_DTYPE = np.dtype([(k, "<i4") for k in ("id", "cnt", "rid", "score", "qs", "qe", "rs", "re", "parent", "subsc", "as", "mlen", "blen", "n_sub", "score0")]
+                     + [("bits", "<u4"), ("hash", "<u4"), ("div", "<f4"), ("reserved", "<u4", (2,))])
 
 
 class ChainDPError(RuntimeError):
@@ -70,6 +75,8 @@ def lib():
         L.chaindp_set_ring.argtypes = [vp, i32]
         L.chaindp_set_variant.argtypes = [vp, i32]
         L.chaindp_backtrack.argtypes = [vp, P, i32, vp, vp, vp, vp]
+        L.chaindp_gen_regs.argtypes = [vp, vp, vp, vp]
+        L.chaindp_est_err.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
         L.chaindp_index_create.restype = vp
         L.chaindp_index_create.argtypes = [i32, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t]
         L.chaindp_index_destroy.restype = None
@@ -197,6 +204,29 @@ class Device:
         b = np.zeros((cap, 2), np.uint64)
         self._check(self._lib.chaindp_backtrack(self._ctx, C.byref(par), min_cnt, _ptr(coff), _ptr(u), _ptr(boff), _ptr(b)))
         return coff, u[:int(coff[-1])], boff, b[:int(boff[-1])]
+
+    # -- chains to hits (mm_gen_regs, hit.c:52-95; mm_est_err, esterr.c:30-64), after backtrack()
+    def gen_regs(self, hash_, qlen, n_chains):
+        """hash_ uint32[n_reads], qlen int32[n_reads] -> REG_DTYPE[n_chains] (n_chains = chains_off[-1] of backtrack())."""
+        hash_ = np.ascontiguousarray(hash_, np.uint32)
+        qlen = np.ascontiguousarray(qlen, np.int32)
+        regs = np.zeros(max(int(n_chains), 1), REG_DTYPE)
+        self._check(self._lib.chaindp_gen_regs(self._ctx, _ptr(hash_), _ptr(qlen), _ptr(regs)))
+        return regs[:int(n_chains)]
+
+    def est_err(self, regs_off, regs, qlen, ref_len, mini_pos_off=None, mini_pos=None):
+        """mm_est_err on the hits `regs` (REG_DTYPE, read r owns regs_off[r]:regs_off[r+1]) -> (regs with div, n_match, n_tot).
+        mini_pos_off / mini_pos None: the minimizer positions collect_seeds() left on the device."""
+        regs_off = np.ascontiguousarray(regs_off, np.int64)
+        regs = np.ascontiguousarray(regs, REG_DTYPE).copy()
+        qlen = np.ascontiguousarray(qlen, np.int32)
+        ref_len = np.ascontiguousarray(ref_len, np.int32)
+        mt = np.zeros((max(len(regs), 1), 2), np.int32)
+        mpo = None if mini_pos_off is None else np.ascontiguousarray(mini_pos_off, np.int64)
+        mp = None if mini_pos is None else np.ascontiguousarray(mini_pos, np.uint64)
+        self._check(self._lib.chaindp_est_err(self._ctx, _ptr(regs_off), _ptr(regs) if len(regs) else None, _ptr(qlen), _ptr(ref_len) if len(ref_len) else None,
+                                              len(ref_len), None if mpo is None else _ptr(mpo), None if mp is None or not len(mp) else _ptr(mp), _ptr(mt)))
+        return regs, mt[:len(regs), 0].copy(), mt[:len(regs), 1].copy()
 
     # -- seed collection on the GPU (collect_seed_hits, map.c:187-236, over the FPGA index image)
     def load_index(self, img):

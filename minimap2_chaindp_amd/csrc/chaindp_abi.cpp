@@ -60,6 +60,15 @@ struct chaindp_ctx {
 	int64_t seed_cap_mini = 0, n_mini_pos = 0;
 	int seed_max_n = -1, seed_max_n2 = -1; // largest reads the two configurations of the LDS sort take on this device
 	int seed_lab_cap = 0;                  // digits k_seed_sort_huge keeps in LDS
+	// chains to hits (allocated on first use, grown with the batch; freed with bot_allocs)
+	void *d_regs = nullptr, *d_reg_counts = nullptr, *d_ref_len = nullptr, *d_mp_up = nullptr;
+	size_t regs_cap = 0, reg_counts_cap = 0, ref_len_cap = 0, mp_up_cap = 0;
+	uint32_t *d_rhash = nullptr;
+	int32_t *d_rqlen = nullptr;
+	int64_t *d_regs_off = nullptr, *d_mp_off_up = nullptr;
+	unsigned long long *d_sum_k = nullptr;
+	int64_t bot_n_reads = -1, bot_n_chains = 0, bot_n_b = 0;   // what the last chaindp_backtrack left resident (-1: nothing of this batch)
+	bool mp_resident = false;                                  // this batch's mini_pos are on the device (it came from chaindp_collect_seeds)
 	// profiling
 	bool prof = false;
 	std::vector<EventSet> pending;
@@ -263,7 +272,7 @@ extern "C" int chaindp_upload(chaindp_ctx_t *ctx, int64_t n_reads, const int64_t
 	if (n_segs_per_read && n_reads)
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_n_segs, n_segs_per_read, (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	ctx->n_reads = n_reads; ctx->total = total; ctx->ran = false;
+	ctx->n_reads = n_reads; ctx->total = total; ctx->ran = false; ctx->bot_n_reads = -1; ctx->mp_resident = false;
 	return CHAINDP_OK;
 }
 
@@ -415,9 +424,112 @@ extern "C" int chaindp_backtrack(chaindp_ctx_t *ctx, const chaindp_params_t *par
 	HIP_TRY(ctx, hipMemcpyAsync(b_off, ctx->bot.b_off, ob, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	const int64_t n_c = ctx->n_reads > 0 ? chains_off[ctx->n_reads] : 0, n_b = ctx->n_reads > 0 ? b_off[ctx->n_reads] : 0;
+	ctx->bot_n_reads = ctx->n_reads; ctx->bot_n_chains = n_c; ctx->bot_n_b = n_b;
 	if (u && n_c > 0) HIP_TRY(ctx, hipMemcpyAsync(u, ctx->bot.u_out, (size_t)n_c * 8, hipMemcpyDeviceToHost, ctx->stream));
 	if (b && n_b > 0) HIP_TRY(ctx, hipMemcpyAsync(b, ctx->bot.b_out, (size_t)n_b * 16, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return CHAINDP_OK;
+}
+
+// grow-only device buffer owned by the context (freed with the backtrack allocations)
+static hipError_t regs_grow(chaindp_ctx *ctx, void *&p, size_t &cap, size_t need)
+{
+	if (need <= cap && p) return hipSuccess;
+	void *q = nullptr;
+	hipError_t e = hipMalloc(&q, need ? need + need / 4 : 8);
+	if (e != hipSuccess) return e;
+	for (void *&old : ctx->bot_allocs) if (old == p && p) { (void)hipFree(p); old = nullptr; }
+	ctx->bot_allocs.push_back(q);
+	p = q; cap = need + need / 4;
+	return hipSuccess;
+}
+
+static int regs_per_read_buffers(chaindp_ctx *ctx)
+{
+	if (ctx->d_rhash) return CHAINDP_OK;
+	const size_t R = (size_t)ctx->cap_reads + 2;
+	HIP_TRY(ctx, bot_alloc(ctx, ctx->d_rhash, R * 4)); HIP_TRY(ctx, bot_alloc(ctx, ctx->d_rqlen, R * 4));
+	HIP_TRY(ctx, bot_alloc(ctx, ctx->d_regs_off, R * 8)); HIP_TRY(ctx, bot_alloc(ctx, ctx->d_mp_off_up, R * 8));
+	HIP_TRY(ctx, bot_alloc(ctx, ctx->d_sum_k, R * 8));
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_gen_regs(chaindp_ctx_t *ctx, const uint32_t *hash, const int32_t *qlen, chaindp_reg_t *regs)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	if (ctx->bot_n_reads < 0 || ctx->bot_n_reads != ctx->n_reads || !ctx->bot.has) { ctx->err = "chaindp_gen_regs needs the chains of a chaindp_backtrack on this batch"; return CHAINDP_ERR_ARG; }
+	const int64_t R = ctx->bot_n_reads, n_c = ctx->bot_n_chains;
+	if (R > 0 && (!hash || !qlen)) { ctx->err = "NULL hash or qlen"; return CHAINDP_ERR_ARG; }
+	if (n_c > 0 && !regs) { ctx->err = "NULL output"; return CHAINDP_ERR_ARG; }
+	if (R == 0 || n_c == 0) return CHAINDP_OK;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc = regs_per_read_buffers(ctx);
+	if (rc) return rc;
+	HIP_TRY(ctx, regs_grow(ctx, ctx->d_regs, ctx->regs_cap, (size_t)n_c * sizeof(chaindp_reg_t)));
+	hipStream_t st = ctx->stream;
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_rhash, hash, (size_t)R * 4, hipMemcpyHostToDevice, st));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_rqlen, qlen, (size_t)R * 4, hipMemcpyHostToDevice, st));
+	// sort keys go to the backtrack's 16-byte scratch (free once the chains are out), range stacks to its stack area
+	HIP_TRY(ctx, chaindp::launch_gen_regs(st, R, ctx->bot.chains_off, ctx->bot.b_off, ctx->bot.u_out, ctx->bot.b_out, ctx->d_rhash, ctx->d_rqlen,
+	                                      ctx->bot.w, ctx->bot.stacks, ctx->d_regs));
+	HIP_TRY(ctx, hipMemcpyAsync(regs, ctx->d_regs, (size_t)n_c * sizeof(chaindp_reg_t), hipMemcpyDeviceToHost, st));
+	HIP_TRY(ctx, hipStreamSynchronize(st));
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_est_err(chaindp_ctx_t *ctx, const int64_t *regs_off, chaindp_reg_t *regs, const int32_t *qlen,
+                               const int32_t *ref_len, int32_t n_ref, const int64_t *mini_pos_off, const uint64_t *mini_pos,
+                               int32_t *match_tot)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	if (ctx->bot_n_reads < 0 || ctx->bot_n_reads != ctx->n_reads || !ctx->bot.has) { ctx->err = "chaindp_est_err needs the chains of a chaindp_backtrack on this batch"; return CHAINDP_ERR_ARG; }
+	const int64_t R = ctx->bot_n_reads;
+	if (R == 0) return CHAINDP_OK;
+	if (!regs_off || !qlen || (n_ref > 0 && !ref_len) || n_ref < 0) { ctx->err = "NULL argument"; return CHAINDP_ERR_ARG; }
+	if (regs_off[0] != 0) { ctx->err = "regs_off must start at 0"; return CHAINDP_ERR_ARG; }
+	for (int64_t r = 0; r < R; ++r) if (regs_off[r + 1] < regs_off[r]) { ctx->err = "regs_off must not decrease"; return CHAINDP_ERR_ARG; }
+	const int64_t n_regs = regs_off[R];
+	if (n_regs == 0) return CHAINDP_OK;
+	if (!regs) { ctx->err = "NULL regs"; return CHAINDP_ERR_ARG; }
+	const bool resident = mini_pos == nullptr && mini_pos_off == nullptr;
+	if (resident && (!ctx->mp_resident || !ctx->d_mp_off)) { ctx->err = "no resident mini_pos: pass the arrays, or collect the seeds with chaindp_collect_seeds"; return CHAINDP_ERR_ARG; }
+	if (!resident && !mini_pos_off) { ctx->err = "mini_pos without offsets"; return CHAINDP_ERR_ARG; }
+	for (int64_t g = 0; g < n_regs; ++g) if (regs[g].cnt < 0 || regs[g].as < 0) { ctx->err = "hit with a negative count or offset"; return CHAINDP_ERR_ARG; }
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc = regs_per_read_buffers(ctx);
+	if (rc) return rc;
+	hipStream_t st = ctx->stream;
+	// every hit's anchors must lie inside its read's chain anchors: checked here, on the host's copy of the offsets
+	{
+		std::vector<int64_t> boff((size_t)R + 1);
+		HIP_TRY(ctx, hipMemcpyAsync(boff.data(), ctx->bot.b_off, (size_t)(R + 1) * 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(ctx, hipStreamSynchronize(st));
+		for (int64_t r = 0; r < R; ++r)
+			for (int64_t g = regs_off[r]; g < regs_off[r + 1]; ++g)
+				if ((int64_t)regs[g].as + regs[g].cnt > boff[r + 1] - boff[r]) { ctx->err = "hit reaches beyond its read's chain anchors"; return CHAINDP_ERR_ARG; }
+	}
+	HIP_TRY(ctx, regs_grow(ctx, ctx->d_regs, ctx->regs_cap, (size_t)n_regs * sizeof(chaindp_reg_t)));
+	HIP_TRY(ctx, regs_grow(ctx, ctx->d_reg_counts, ctx->reg_counts_cap, (size_t)n_regs * 8));
+	HIP_TRY(ctx, regs_grow(ctx, ctx->d_ref_len, ctx->ref_len_cap, (size_t)(n_ref > 0 ? n_ref : 1) * 4));
+	const int64_t *d_mpo = ctx->d_mp_off;
+	const unsigned long long *d_mp = ctx->d_mini_pos;
+	if (!resident) {
+		const int64_t n_mp = mini_pos_off[R];
+		if (n_mp < 0 || (n_mp > 0 && !mini_pos)) { ctx->err = "mini_pos announced but absent"; return CHAINDP_ERR_ARG; }
+		HIP_TRY(ctx, regs_grow(ctx, ctx->d_mp_up, ctx->mp_up_cap, (size_t)(n_mp > 0 ? n_mp : 1) * 8));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mp_off_up, mini_pos_off, (size_t)(R + 1) * 8, hipMemcpyHostToDevice, st));
+		if (n_mp > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mp_up, mini_pos, (size_t)n_mp * 8, hipMemcpyHostToDevice, st));
+		d_mpo = ctx->d_mp_off_up; d_mp = (const unsigned long long*)ctx->d_mp_up;
+	}
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_regs_off, regs_off, (size_t)(R + 1) * 8, hipMemcpyHostToDevice, st));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_rqlen, qlen, (size_t)R * 4, hipMemcpyHostToDevice, st));
+	if (n_ref > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ref_len, ref_len, (size_t)n_ref * 4, hipMemcpyHostToDevice, st));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_regs, regs, (size_t)n_regs * sizeof(chaindp_reg_t), hipMemcpyHostToDevice, st));
+	HIP_TRY(ctx, chaindp::launch_est_err(st, R, n_regs, ctx->d_regs_off, ctx->bot.b_off, ctx->bot.b_out, ctx->d_rqlen, (const int32_t*)ctx->d_ref_len, n_ref,
+	                                     d_mpo, d_mp, ctx->d_sum_k, ctx->d_regs, (int32_t*)ctx->d_reg_counts));
+	HIP_TRY(ctx, hipMemcpyAsync(regs, ctx->d_regs, (size_t)n_regs * sizeof(chaindp_reg_t), hipMemcpyDeviceToHost, st));
+	if (match_tot) HIP_TRY(ctx, hipMemcpyAsync(match_tot, ctx->d_reg_counts, (size_t)n_regs * 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(ctx, hipStreamSynchronize(st));
 	return CHAINDP_OK;
 }
 
@@ -525,7 +637,7 @@ extern "C" int chaindp_upload_gather_ex(chaindp_ctx_t *ctx, int64_t n_reads, con
 	if (n_segs_per_read && n_reads)
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_n_segs, n_segs_per_read, (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // the host arrays (off, pointers) may go away after the call
-	ctx->n_reads = n_reads; ctx->total = total; ctx->ran = false;
+	ctx->n_reads = n_reads; ctx->total = total; ctx->ran = false; ctx->bot_n_reads = -1; ctx->mp_resident = false;
 	return CHAINDP_OK;
 }
 
@@ -561,7 +673,7 @@ extern "C" int chaindp_upload_gather(chaindp_ctx_t *ctx, int64_t n_reads, const 
 	if (n_segs_per_read && n_reads)
 		HIP_TRY(ctx, hipMemcpyAsync(ctx->d_n_segs, n_segs_per_read, (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	ctx->n_reads = n_reads; ctx->total = total; ctx->ran = false;
+	ctx->n_reads = n_reads; ctx->total = total; ctx->ran = false; ctx->bot_n_reads = -1; ctx->mp_resident = false;
 	return CHAINDP_OK;
 }
 
@@ -721,7 +833,7 @@ static int collect_seeds_impl(chaindp_ctx *ctx, const chaindp_index_t *ix, int f
 	HIP_TRY(ctx, hipMemcpyAsync(totals, ctx->seed.totals, 16, hipMemcpyDeviceToHost, st));
 	HIP_TRY(ctx, hipStreamSynchronize(st));
 	if ((int64_t)totals[0] > ctx->cap_anchors) {
-		ctx->n_reads = 0; ctx->total = 0; ctx->ran = false;
+		ctx->n_reads = 0; ctx->total = 0; ctx->ran = false; ctx->bot_n_reads = -1; ctx->mp_resident = false;
 		ctx->err = "the batch's seeds exceed the anchor capacity the context was created with";
 		return CHAINDP_ERR_CAPACITY;
 	}
@@ -748,7 +860,7 @@ static int collect_seeds_impl(chaindp_ctx *ctx, const chaindp_index_t *ix, int f
 	if (mini_pos_off) HIP_TRY(ctx, hipMemcpyAsync(mini_pos_off, ctx->d_mp_off, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, st));
 	if (rep_len && n_reads) HIP_TRY(ctx, hipMemcpyAsync(rep_len, ctx->d_rep_len, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(ctx, hipStreamSynchronize(st));
-	ctx->n_reads = n_reads; ctx->total = (int64_t)totals[0]; ctx->n_mini_pos = (int64_t)totals[1]; ctx->ran = false;
+	ctx->n_reads = n_reads; ctx->total = (int64_t)totals[0]; ctx->n_mini_pos = (int64_t)totals[1]; ctx->ran = false; ctx->bot_n_reads = -1; ctx->mp_resident = true;
 	return CHAINDP_OK;
 }
 

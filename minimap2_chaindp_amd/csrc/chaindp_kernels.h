@@ -82,6 +82,13 @@ struct BottomScratch {
 hipError_t launch_backtrack(hipStream_t st, int min_cnt, int min_sc, int64_t n_reads, int64_t m_cap, const int64_t *d_soff, const void *d_seeds,
                             const unsigned long long *d_n_seeds, BottomScratch sc, int64_t n_seeds_host);
 
+// chains to hits (mm_gen_regs, hit.c:52-95; mm_est_err, esterr.c:30-64): chaindp_regs.hip
+hipError_t launch_gen_regs(hipStream_t st, int64_t n_reads, const int64_t *d_chains_off, const int64_t *d_b_off, const unsigned long long *d_u,
+                           const void *d_b, const uint32_t *d_hash, const int32_t *d_qlen, void *d_z, void *d_stacks, void *d_regs);
+hipError_t launch_est_err(hipStream_t st, int64_t n_reads, int64_t n_regs, const int64_t *d_regs_off, const int64_t *d_b_off, const void *d_b,
+                          const int32_t *d_qlen, const int32_t *d_ref_len, int32_t n_ref, const int64_t *d_mp_off, const unsigned long long *d_mini_pos,
+                          unsigned long long *d_sum_k, void *d_regs, int32_t *d_counts);
+
 // seed collection on the GPU (reference map.c:112-236 over the FPGA index image, index.c:603-720): chaindp_seed.hip
 struct SeedIndex {                   // the four blobs of the image in HBM (layout: seed_collect.h)
 	const uint8_t *B, *H, *V, *P;
