@@ -567,6 +567,15 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 					head[4 * wl + 2] = start[4 * wl + 2] = (uint16_t)acc; acc += c2; tail[4 * wl + 2] = (uint16_t)acc;
 					head[4 * wl + 3] = start[4 * wl + 3] = (uint16_t)acc; acc += c3; tail[4 * wl + 3] = (uint16_t)acc;
 					n_digits = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+					{                                                                // the digits in use, ascending, where the counts were
+						int at = n_digits;
+						for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(at, d); if (wl >= d) at += t; }
+						at -= n_digits;
+						if (c0) cnt[at++] = 4 * wl;
+						if (c1) cnt[at++] = 4 * wl + 1;
+						if (c2) cnt[at++] = 4 * wl + 2;
+						if (c3) cnt[at++] = 4 * wl + 3;
+					}
 					d_lo = c0 ? 4 * wl : c1 ? 4 * wl + 1 : c2 ? 4 * wl + 2 : c3 ? 4 * wl + 3 : 256;
 					d_hi = c3 ? 4 * wl + 3 : c2 ? 4 * wl + 2 : c1 ? 4 * wl + 1 : c0 ? 4 * wl : -1;
 					for (int d = 32; d > 0; d >>= 1) {
@@ -628,7 +637,8 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 						run += __popcll(m);
 					}
 				} else if (wl == 0) {
-					for (int d = 0; d < 256; ++d) {
+					for (int di = 0; di < n_digits; ++di) {                          // empty buckets have nothing to place
+						const int d = (int)cnt[di];
 						int hd = head[d];
 						const int td = tail[d];
 						while (hd != td) {
