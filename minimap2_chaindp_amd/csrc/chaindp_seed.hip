@@ -420,15 +420,16 @@ __global__ __launch_bounds__(256) void k_seed_sort_huge(int64_t n_reads, int min
 	}
 }
 
-// radix_sort_128x (ksort.h:101-151) of one read (or one bucket handed over by k_seed_sort_huge) by one workgroup of four
+// radix_sort_128x (ksort.h:101-151) of one read (or one bucket handed over by k_seed_sort_huge) by one workgroup of sixteen
 // waves, in LDS, on (key, original index) pairs.  A read whose keys all differ -- almost every read -- has a unique
 // sorted order and is done by a bitonic network.  Otherwise the reference's procedure is followed level by level:
 // ranges of more than 64 anchors go to the waves one at a time (digit counts by the wave, the bucket permutation
 // replayed over the digits by one lane, keys and indices moved by the wave), ranges of up to 64 are insertion-sorted
 // one per thread, and a level on which every key of a range has the same digit is skipped (the reference's pass
 // over it moves nothing).  Positions are 16-bit: a read here has at most max_n2 <= 65535 anchors.
-// LDS: keys[n] u64 | idx[n] u16 | 4 x (head, tail, start)[256] u16 | 4 x counts[256] u32 | two queues of ranges |
-// 4 counters | digits[n] u8, with n = max_n (<= 8192, 1024 queue slots for small ranges) or max_n2 (~13 k, 256 slots),
+// LDS: keys[n] u64 | idx[n] u16 | W x (head, tail, start)[256] u16 | W x counts[256] u32 | two queues of ranges |
+// 4 counters | digits[n] u8, with n = max_n (<= 8192, W = 16 waves with tables, 1024 queue slots for small ranges) or
+// max_n2 (~13 k, W = 4, 256 slots),
 // chosen per read inside one launch.
 // A queue keeps its first n / 65 + 2 slots for ranges of more than 64 anchors (they are disjoint, so they always fit);
 // small ranges that find the rest full are insertion-sorted on the spot by the lane that made them.
@@ -450,7 +451,9 @@ __device__ __forceinline__ void seed_isort(uint64_t *key, uint16_t *idx, int beg
 
 // takes the reads (and work items) of up to max_n2 anchors: with 32 bucket tables and 8 wave-wide histograms up to max_n
 // anchors, with 4 and 2 above (the LDS layout is chosen per read; the launch reserves the larger of the two)
-#define SEED_TPB 256
+#define SEED_TPB 1024
+// waves that have bucket tables (and so take large ranges): all sixteen for reads of the first configuration, four for the second
+__host__ __device__ inline int seed_table_waves(int workers) { return workers >= 32 ? SEED_TPB / 64 : 4; }
 __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max_n, int max_n2, int try_network, const int64_t *__restrict__ off,
                                                   const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ a,
                                                   const SeedItem *__restrict__ items, const unsigned long long *__restrict__ n_items)
@@ -471,11 +474,12 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 		const int cap_n = n <= max_n ? max_n : max_n2;
 		const int q_big = seed_big_slots(cap_n), q_slots = q_big + seed_small_slots(n <= max_n ? 32 : 4);
 		const int wave = lane >> 6, wl = lane & 63;
+		const int n_tab = seed_table_waves(n <= max_n ? 32 : 4), tw = wave < n_tab ? wave : 0;
 		uint64_t *key = seed_lds;
 		uint16_t *idx = (uint16_t*)(key + cap_n);
-		uint16_t *head = idx + cap_n + wave * 768, *tail = head + 256, *start = tail + 256;   // one set of bucket tables per wave
-		unsigned int *cnt = (unsigned int*)(idx + cap_n + (SEED_TPB / 64) * 768) + wave * 256;   // and one set of digit counts
-		SeedRange *qbase = (SeedRange*)(cnt - wave * 256 + (SEED_TPB / 64) * 256);
+		uint16_t *head = idx + cap_n + tw * 768, *tail = head + 256, *start = tail + 256;      // one set of bucket tables per wave that takes ranges
+		unsigned int *cnt = (unsigned int*)(idx + cap_n + n_tab * 768) + tw * 256;              // and one set of digit counts
+		SeedRange *qbase = (SeedRange*)(cnt - tw * 256 + n_tab * 256);
 		int *qn = (int*)(qbase + 2 * q_slots);                             // [parity][0 = big ranges, 1 = small ranges]
 		uint8_t *lab = (uint8_t*)(qn + 4);                                 // cap_n: the current digit of every position
 		ulonglong2 *ag = a + b;                                            // this read's output range doubles as scratch until the final gather
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 				const SeedRange rg = cur[q_big + w];
 				seed_isort(key, idx, rg.beg, rg.end);
 			}
-			for (int w = wave; w < n_big; w += SEED_TPB / 64) {                      // a wave per large range
+			for (int w = wave; w < n_big && wave < n_tab; w += n_tab) {              // a wave per large range
 				const SeedRange rg = cur[w];
 				const int rb = rg.beg, re = rg.end, len = re - rb, sh = rg.shift, next = sh > 8 ? sh - 8 : 0;
 				if (len <= 64) { if (wl == 0) seed_isort(key, idx, rb, re); continue; }       // ksort.h:143 (a whole read of <= 64 anchors)
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 size_t seed_sort_lds_bytes(int max_n, int workers, int coop)
 {
 	(void)coop;
-	return (((size_t)max_n * 10 + 7) & ~(size_t)7) + (size_t)(SEED_TPB / 64) * (768 * 2 + 256 * 4)
+	return (((size_t)max_n * 10 + 7) & ~(size_t)7) + (size_t)seed_table_waves(workers) * (768 * 2 + 256 * 4)
 	       + 2 * (size_t)(seed_big_slots(max_n) + seed_small_slots(workers)) * sizeof(SeedRange) + 16 + (((size_t)max_n + 7) & ~(size_t)7);
 }
 
