@@ -13,6 +13,7 @@ from minimap2_chaindp_amd import anchorgen as ag, chaindp, params as P
 
 pytestmark = pytest.mark.gpu
 SEEDS = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seeds", "*.npz")))
+REGS = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regs", "*.npz")))
 DIV_RTOL = 2e-6
 
 
@@ -61,6 +62,27 @@ def test_fixture_minimizers_to_hits_without_leaving_the_device(dev, path):
         e, em, et = ol.oracle_est_err(ref_len, int(g["qlen"][r]), exp[r], b[boff[r]:boff[r + 1]], mp[mpo[r]:mpo[r + 1]])
         s = slice(int(coff[r]), int(coff[r + 1]))
         check_div(got[s], n_match[s], n_tot[s], e, em, et, r)
+
+
+@pytest.mark.parametrize("path", REGS, ids=[os.path.basename(p)[:-4] for p in REGS])
+def test_hits_match_the_committed_reference_records(dev, path):
+    """From the fixture's anchors to the reference's own mm_gen_regs / mm_est_err records (tests/golden/regs/*.npz, made by
+    the unmodified reference): DP, new_seed[], chains and hits on the GPU."""
+    k = np.load(path, allow_pickle=False)
+    g = np.load(os.path.join(os.path.dirname(os.path.dirname(path)), "seeds", os.path.basename(path)), allow_pickle=False)
+    pv = [int(x) for x in g["params"]]
+    par = P.ChainParams(max_dist_x=pv[0], max_dist_y=pv[1], bw=pv[2], max_skip=pv[3], min_sc=pv[4], is_cdna=pv[5], n_segs=1)
+    dev.chain_batch(par, g["a_off"], g["anchors"])
+    dev.compact(par)
+    coff, u, boff, b = dev.backtrack(par, int(k["min_cnt"]))
+    assert np.array_equal(coff, k["chains_off"]) and np.array_equal(u, k["u"]) and np.array_equal(b, k["b"].reshape(-1, 2))
+    regs = dev.gen_regs(k["hash"], k["qlen"], coff[-1])
+    exp, exp_div = k["regs"].view(ol.REG_DTYPE).reshape(-1), k["regs_div"].view(ol.REG_DTYPE).reshape(-1)
+    assert regs.tobytes() == exp.tobytes(), "mm_gen_regs"
+    got, n_match, n_tot = dev.est_err(coff, regs, k["qlen"], k["ref_len"], g["mp_off"], g["mini_pos"])
+    unset = exp_div["div"] < 0
+    assert np.array_equal(got["div"] < 0, unset) and np.allclose(got["div"][~unset], exp_div["div"][~unset], rtol=DIV_RTOL, atol=0)
+    assert (n_match[~unset] >= 1).all() and (n_tot[~unset] >= n_match[~unset]).all()
 
 
 def _mini_pos_for(rng, qlen, b):
