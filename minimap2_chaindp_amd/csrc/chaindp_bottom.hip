@@ -179,7 +179,7 @@ __global__ __launch_bounds__(BT_BLOCK) void k_bt_rank(int64_t n_reads, const int
 // Reads whose records fit the LDS (p and owner, 8 B per record) get B6+B7 from one workgroup working in LDS
 // (k_bt_read_lds, launched twice: reads of up to BT_LDS_RECS records at two workgroups per CU, reads of up to
 // BT_LDS_RECS_MAX at one); the global-memory kernels below only serve the still longer reads.
-#define BT_LDS_RECS 8192
+#define BT_LDS_RECS 10112   // 2 x (8 B x 10112 + 1 KB) = the CU's 160 KB: still two workgroups per CU
 #define BT_LDS_RECS_MAX 20000
 
 // B6+B7 for one read per workgroup, in LDS: owner by LDS atomicMin walkers (one thread per chain), then length,
