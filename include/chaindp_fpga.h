@@ -103,16 +103,7 @@ void chaindp_fpga_configure(int n_gpus, int max_packets_per_batch, unsigned long
 /* Counters since fpga_init: st[0] packets, st[1] reads, st[2] anchors, st[3] device batches,
  * st[4] reads answered err_flag=1. */
 void chaindp_fpga_stats(int64_t st[5]);
-/* A host-side statement of the seed collection the GPU does for minimizer packets (type 3), callable on its own (no
- * GPU involved; tests and tools): collect_seed_hits of the reference (map.c:187-236) for one read, over the index image received
- * through fpga_load_index (types 4..7, index.c:603-720) with the flag / max_occ of fpga_set_params (main.c:243).
- * mini = the read's minimizers as collect_minimizers leaves them (map.c:352), bid / qlen as in collect_task_t.
- * Writes up to cap_anchors sorted anchors and *n_anchors (the count needed, also when it exceeds the capacity),
- * *rep_len, and up to n_mini entries of mini_pos with *n_mini_pos.  Returns 0, -1 without a complete index image,
- * -2 when cap_anchors was too small. */
-int chaindp_fpga_collect_seeds(uint32_t bid, int qlen, const chaindp_anchor_t *mini, int64_t n_mini,
-                               chaindp_anchor_t *anchors, int64_t cap_anchors, int64_t *n_anchors,
-                               int *rep_len, uint64_t *mini_pos, int *n_mini_pos);
+
 
 #ifdef __cplusplus
 }

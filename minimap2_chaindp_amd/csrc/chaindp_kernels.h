@@ -90,7 +90,13 @@ hipError_t launch_est_err(hipStream_t st, int64_t n_reads, int64_t n_regs, const
                           unsigned long long *d_sum_k, void *d_regs, int32_t *d_counts);
 
 // seed collection on the GPU (reference map.c:112-236 over the FPGA index image, index.c:603-720): chaindp_seed.hip
-struct SeedIndex {                   // the four blobs of the image in HBM (layout: seed_collect.h)
+// The four blobs of the image, as index.c:603-720 writes them:
+//   B: per hash bucket 16 bytes: w0 = (p_off & 0xff) << 56 | n_buckets << 24;  w1 = h_off << 28 | p_off >> 8
+//      (h_off in hash slots, rounded up to 8 per bucket; p_off in entries of P; an empty bucket is all zero)
+//   H: per 8 hash slots 64 bytes: 4 B khash flag word (2 bits per slot, 16 slots), 8 x 6 B keys (low 48 bits), 12 B pad
+//   V: per hash slot 8 bytes: the khash value (a position if the key's bit 0 is set, else p index << 32 | count)
+//   P: 8 bytes per position
+struct SeedIndex {                   // the four blobs in HBM
 	const uint8_t *B, *H, *V, *P;
 	uint64_t nB, nH, nV, nP;         // bytes
 	int b_bits;                      // log2 of the bucket count

@@ -14,7 +14,8 @@
 //                  chaining DP, so a read with equal keys is sorted by the reference's procedure step by step; a
 //                  read without (the common case) by a bitonic network.
 //   k_seed_sort_huge  workgroup per read too large for LDS: top levels in global memory, buckets back to k_seed_sort
-// Image layout: see csrc/seed_collect.h (the host-side statement of the same lookup, pinned on the CPU tier).
+// Image layout: see SeedIndex in chaindp_kernels.h.  A CPU restatement of the same lookup, pinned against the reference, is
+// the checker of these kernels (oracle/seed_oracle.cpp; test infrastructure, not part of this library).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

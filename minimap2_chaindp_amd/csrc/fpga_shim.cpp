@@ -24,7 +24,6 @@
 #include <unordered_map>
 #include <vector>
 #include "../../include/chaindp_fpga.h"
-#include "seed_collect.h"
 
 static_assert(sizeof(chaindp_pkt_hdr_t) == 64, "chaindp_sndhdr_t must be 64 bytes (reference main.c:296-302)");
 static_assert(sizeof(chaindp_pkt_task_t) == 64, "collect_task_t must be 64 bytes");
@@ -75,13 +74,34 @@ private:
 struct Submitted { void *buf; uint32_t size; };
 struct Result { void *buf; int size; };
 
+
+// The index image as the reference streams it (index.c:102-119: blobs B, H, V, P as types 4..7, in chunks, in this order
+// for every index part).  The shim only keeps the bytes until a service context copies them to HBM
+// (chaindp_index_create); the lookup itself runs on the GPU (chaindp_seed.hip).
+class IndexImage {
+public:
+	void append(int type, const void *data, size_t bytes)
+	{
+		std::vector<uint8_t> *dst = type == 4 ? &blob_[0] : type == 5 ? &blob_[1] : type == 6 ? &blob_[2] : type == 7 ? &blob_[3] : nullptr;
+		if (!dst || !data || bytes == 0) return;
+		// a B chunk after the rest of an image has arrived starts the image of the next index part
+		if (type == 4 && (!blob_[1].empty() || !blob_[2].empty() || !blob_[3].empty())) clear();
+		const uint8_t *p = (const uint8_t*)data;
+		dst->insert(dst->end(), p, p + bytes);
+	}
+	bool complete() const { return !blob_[0].empty() && !blob_[1].empty() && !blob_[2].empty(); }
+	void clear() { for (auto &b : blob_) b.clear(); }
+	const std::vector<uint8_t> &blob(int k) const { return blob_[k]; }   // 0..3 = B, H, V, P
+private:
+	std::vector<uint8_t> blob_[4];
+};
 struct Service {
 	bool up = false;
 	int n_gpus_cfg = 0, max_packets = 64, services_per_gpu = 2;
 	unsigned long max_inflight = 1ul << 30;
 	// fpga_set_params (main.c:243)
 	int bw = 500, is_cdna = 0, max_skip = 25, min_sc = 40, flag = 0, max_occ = 0;
-	chaindp::IndexImage index;         // fpga_load_index (main.c:201-204): the image minimizer packets are looked up in
+	IndexImage index;                  // fpga_load_index (main.c:201-204): the image minimizer packets are looked up in
 	uint64_t index_gen = 0;            // bumped by every fpga_load_index call: service threads refresh their device copy
 	PinnedPool pool;
 	std::mutex mu;
@@ -411,35 +431,12 @@ extern "C" void fpga_set_params(int bw, int is_cdna, int max_skip, int min_sc, i
 extern "C" void fpga_load_index(void *addr, int size, int type)
 {
 	// index.c:102-119 streams the B/H/V/P index image (types 4..7) to the FPGA, which did the seed lookup itself.
-	// Here the lookup runs on the shim's host threads (seed_collect.cpp) for packets that still carry minimizers
-	// (type 3, the unmodified reference); anchor packets (type 0x41) do not need the image.
+	// Here the image is kept until a service context copies it to HBM, where the lookup runs (chaindp_seed.hip) for
+	// packets that carry minimizers (type 3, the unmodified reference); anchor packets (type 0x41) do not need it.
 	if (!addr || size <= 0) return;
 	std::lock_guard<std::mutex> lk(g.mu);
 	g.index.append(type, addr, (size_t)size);
 	++g.index_gen;
-}
-
-extern "C" int chaindp_fpga_collect_seeds(uint32_t bid, int qlen, const chaindp_anchor_t *mini, int64_t n_mini,
-                                          chaindp_anchor_t *anchors, int64_t cap_anchors, int64_t *n_anchors,
-                                          int *rep_len, uint64_t *mini_pos, int *n_mini_pos)
-{
-	int flag, max_occ;
-	{
-		std::lock_guard<std::mutex> lk(g.mu);
-		if (!g.index.complete()) return -1;
-		flag = g.flag; max_occ = g.max_occ;
-	}
-	std::vector<chaindp::U128> a;
-	std::vector<uint64_t> mp;
-	int rl = 0;
-	chaindp::collect_seed_hits(g.index, flag, max_occ, (const chaindp::U128*)mini, (size_t)(n_mini > 0 ? n_mini : 0), bid, qlen, a, &rl, mp);
-	if (n_anchors) *n_anchors = (int64_t)a.size();
-	if (rep_len) *rep_len = rl;
-	if (n_mini_pos) *n_mini_pos = (int)mp.size();
-	if (mini_pos && !mp.empty()) memcpy(mini_pos, mp.data(), mp.size() * sizeof(uint64_t));
-	if ((int64_t)a.size() > cap_anchors) return -2;
-	if (anchors && !a.empty()) memcpy(anchors, a.data(), a.size() * sizeof(chaindp_anchor_t));
-	return 0;
 }
 
 extern "C" void *fpga_get_writebuf_thread(unsigned long size, int type, int tid)

@@ -74,9 +74,6 @@ def lib():
         L.chaindp_fpga_configure.argtypes = [C.c_int, C.c_int, C.c_ulong]
         L.chaindp_fpga_stats.restype = None
         L.chaindp_fpga_stats.argtypes = [vp]
-        L.chaindp_fpga_collect_seeds.restype = C.c_int
-        L.chaindp_fpga_collect_seeds.argtypes = [C.c_uint32, C.c_int, vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_int64),
-                                                 C.POINTER(C.c_int), vp, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -148,25 +145,6 @@ def load_index(img):
         blob = np.ascontiguousarray(blob, np.uint8)
         if blob.size:
             L.fpga_load_index(blob.ctypes.data, int(blob.size), 4 + k)      # TYPE_INDEX_B.. (fpga.h:20-23)
-
-
-def collect_seeds(bid, qlen, mini):
-    """The shim's host-side collect_seed_hits for one read -> (anchors uint64[n,2], rep_len, mini_pos uint64[])."""
-    L = lib()
-    mini = np.ascontiguousarray(mini, np.uint64).reshape(-1, 2)
-    n, rl, nmp = C.c_int64(0), C.c_int(0), C.c_int(0)
-    mp = np.zeros(len(mini) + 1, np.uint64)
-    cap = 1 << 12
-    while True:
-        out = np.zeros((cap, 2), np.uint64)
-        rc = L.chaindp_fpga_collect_seeds(int(bid), int(qlen), mini.ctypes.data, len(mini), out.ctypes.data, cap,
-                                          C.byref(n), C.byref(rl), mp.ctypes.data, C.byref(nmp))
-        if rc == -2:
-            cap = int(n.value)
-            continue
-        if rc != 0:
-            raise chaindp.ChainDPError("chaindp_fpga_collect_seeds: no complete index image (fpga_load_index types 4..7)")
-        return out[:n.value].copy(), rl.value, mp[:nmp.value].copy()
 
 
 def build_result_packet_for_test(hdr, items):

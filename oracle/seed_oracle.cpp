@@ -1,9 +1,9 @@
-// seed_collect.cpp -- see seed_collect.h.  Every routine cites the reference lines it restates.
-#include "seed_collect.h"
+// seed_oracle.cpp -- see seed_oracle.h (TEST INFRASTRUCTURE ONLY).  Every routine cites the reference lines it restates.
+#include "seed_oracle.h"
 
 #include <string.h>
 
-namespace chaindp {
+namespace seedoracle {
 
 namespace {
 
@@ -243,4 +243,34 @@ void collect_seed_hits(const IndexImage &idx, int flag, int max_occ, const U128 
 	radix_sort_128x(a.data(), a.data() + a.size());                    // map.c:233
 }
 
-} // namespace chaindp
+} // namespace seedoracle
+
+// ---- C entry points for tests/oracle_lib.py -------------------------------------------------------------------
+
+extern "C" void *so_index_create(const void *B, size_t nB, const void *H, size_t nH, const void *V, size_t nV, const void *P, size_t nP)
+{
+	seedoracle::IndexImage *ix = new seedoracle::IndexImage();
+	ix->append(4, B, nB); ix->append(5, H, nH); ix->append(6, V, nV); ix->append(7, P, nP);
+	if (!ix->complete()) { delete ix; return nullptr; }
+	return ix;
+}
+
+extern "C" void so_index_destroy(void *ix) { delete (seedoracle::IndexImage*)ix; }
+
+// collect_seed_hits for one read.  Returns 0, or -2 when cap_anchors is too small (*n_anchors holds the need).
+extern "C" int so_collect_seed_hits(const void *ix, int flag, int max_occ, uint32_t bid, int qlen, const void *mini, int64_t n_mini,
+                                    void *anchors, int64_t cap_anchors, int64_t *n_anchors, int *rep_len, uint64_t *mini_pos, int *n_mini_pos)
+{
+	std::vector<seedoracle::U128> a;
+	std::vector<uint64_t> mp;
+	int rl = 0;
+	seedoracle::collect_seed_hits(*(const seedoracle::IndexImage*)ix, flag, max_occ, (const seedoracle::U128*)mini, (size_t)(n_mini > 0 ? n_mini : 0),
+	                              bid, qlen, a, &rl, mp);
+	if (n_anchors) *n_anchors = (int64_t)a.size();
+	if (rep_len) *rep_len = rl;
+	if (n_mini_pos) *n_mini_pos = (int)mp.size();
+	if (mini_pos && !mp.empty()) memcpy(mini_pos, mp.data(), mp.size() * sizeof(uint64_t));
+	if ((int64_t)a.size() > cap_anchors) return -2;
+	if (anchors && !a.empty()) memcpy(anchors, a.data(), a.size() * 16);
+	return 0;
+}

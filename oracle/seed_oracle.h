@@ -1,18 +1,18 @@
-// seed_collect.h -- the index image of the packet shim, and a host-side statement of seed collection over it.
+// seed_oracle.h -- CPU restatement of the reference's seed collection (collect_seed_hits, map.c:112-236, with
+// mm_idx_get, index.c:221-238, over the FPGA index image of index.c:603-720, and radix_sort_128x, ksort.h:101-151).
 //
-// The reference's FPGA received minimizers and looked the seeds up itself, in an index image the host streams to
-// it through fpga_load_index (index.c:603-720 builds the image, main.c:201-204 sends it as types 4..7).  The
-// shim keeps the image (IndexImage) and has the GPU do that lookup (chaindp_seed.hip).  collect_seed_hits below is
-// the same computation on the host (map.c:112-236), exported as chaindp_fpga_collect_seeds for tools and for the
-// CPU test tier, where it is pinned against the reference's own results; the product's packet path does not use it.
-#ifndef CHAINDP_SEED_COLLECT_H
-#define CHAINDP_SEED_COLLECT_H
+// TEST INFRASTRUCTURE ONLY, like the rest of oracle/: tests/ load libseedoracle.so as the checker of the GPU's seed
+// collection (minimap2_chaindp_amd/csrc/chaindp_seed.hip); the product never links or calls it.
+// Parity status: PINNED against the reference's own collect_seed_hits results (tests/golden/seeds/*.npz, produced by
+// oracle/mt_dump.c from the unmodified reference): tests/test_seed_collect.py.
+#ifndef SEED_ORACLE_H
+#define SEED_ORACLE_H
 
 #include <stddef.h>
 #include <stdint.h>
 #include <vector>
 
-namespace chaindp {
+namespace seedoracle {
 
 struct U128 { uint64_t x, y; };   // mm128_t (minimap.h:48)
 
@@ -24,7 +24,7 @@ struct U128 { uint64_t x, y; };   // mm128_t (minimap.h:48)
 //   P: 8 bytes per position
 class IndexImage {
 public:
-	void append(int type, const void *data, size_t bytes);   // fpga_load_index chunks, type 4..7 (fpga.h:20-23)
+	void append(int type, const void *data, size_t bytes);   // a blob or a chunk of one, type 4..7 = B, H, V, P (fpga.h:20-23)
 	bool complete() const { return !B_.empty() && !H_.empty() && !V_.empty(); }
 	void clear();
 	// mm_idx_get (index.c:221-238) over the image: positions of minimizer `minier`, *n of them (0 if absent)
@@ -47,5 +47,5 @@ void collect_seed_hits(const IndexImage &idx, int flag, int max_occ, const U128 
 // procedure is followed step by step.
 void radix_sort_128x(U128 *beg, U128 *end);
 
-} // namespace chaindp
+} // namespace seedoracle
 #endif

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libmm2chain_ref.so")
 CAP_SO = os.path.join(ROOT, "oracle", "_ref", "libmm2chain_cap.so")
+SEED_SO = os.path.join(ROOT, "oracle", "libseedoracle.so")
 
 SEED_DTYPE = np.dtype([("x", "<u8"), ("y", "<u8"), ("p", "<i4"), ("f", "<i4")])  # struct new_seed, 24 B
 assert SEED_DTYPE.itemsize == 24
@@ -220,6 +221,64 @@ def ref_est_err(ref_len, qlen, regs, b, mini_pos):
     out = np.zeros(n, REG_DTYPE)
     out.view(np.uint8).reshape(n, 80)[:, :72] = raw[:, :72]
     return out
+
+
+# ---- seed collection (collect_seed_hits, map.c:112-236, over the FPGA index image): oracle/seed_oracle.cpp ----
+
+_seed = None
+
+
+def seed_oracle():
+    global _seed
+    if _seed is None:
+        lib = C.CDLL(SEED_SO)
+        lib.so_index_create.restype = C.c_void_p
+        lib.so_index_create.argtypes = [C.c_void_p, C.c_size_t] * 4
+        lib.so_index_destroy.restype = None
+        lib.so_index_destroy.argtypes = [C.c_void_p]
+        lib.so_collect_seed_hits.restype = C.c_int
+        lib.so_collect_seed_hits.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                             C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int)]
+        _seed = lib
+    return _seed
+
+
+class SeedIndex:
+    """The reference's index image (blobs B, H, V, P of index.c:603-720) opened by the CPU restatement."""
+
+    def __init__(self, blobs):
+        self._blobs = [np.ascontiguousarray(b, np.uint8) for b in blobs]
+        args = sum(([b.ctypes.data if b.size else None, int(b.size)] for b in self._blobs), [])
+        self._h = seed_oracle().so_index_create(*args)
+        if not self._h:
+            raise ValueError("incomplete index image (B, H and V blobs are required)")
+
+    def close(self):
+        if self._h:
+            seed_oracle().so_index_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def collect_seeds(self, flag, max_occ, bid, qlen, mini):
+        """collect_seed_hits for one read -> (anchors uint64[n,2] sorted as radix_sort_128x leaves them, rep_len, mini_pos uint64[])."""
+        mini = np.ascontiguousarray(mini, np.uint64).reshape(-1, 2)
+        n, rl, nmp = C.c_int64(0), C.c_int(0), C.c_int(0)
+        mp = np.zeros(len(mini) + 1, np.uint64)
+        cap = 1 << 12
+        while True:
+            out = np.zeros((cap, 2), np.uint64)
+            rc = seed_oracle().so_collect_seed_hits(self._h, int(flag), int(max_occ), int(bid), int(qlen), mini.ctypes.data, len(mini),
+                                                    out.ctypes.data, cap, C.byref(n), C.byref(rl), mp.ctypes.data, C.byref(nmp))
+            if rc == -2:
+                cap = int(n.value)
+                continue
+            assert rc == 0
+            return out[:n.value].copy(), rl.value, mp[:nmp.value].copy()
 
 
 # ---- batch calls -------------------------------------------------------------

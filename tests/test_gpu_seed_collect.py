@@ -138,7 +138,6 @@ def _build_image(rng, n_keys, max_cnt, b_bits=6, rid_pool=None, pos_bits=21):
 
 
 def _synthetic_case(seed, max_cnt, n_mini, rep_pct, rid_pool=None, pos_bits=21, quiet=False):
-    from minimap2_chaindp_amd import fpga
     rng = np.random.default_rng(seed)
     blobs, keys = _build_image(rng, 3000, max_cnt, rid_pool=rid_pool, pos_bits=pos_bits)
     n_reads, flag, max_occ = 6, int(rng.choice([0, 3, 0x100000])), int(max_cnt * 3 // 4 + 2)
@@ -156,10 +155,8 @@ def _synthetic_case(seed, max_cnt, n_mini, rep_pct, rid_pool=None, pos_bits=21, 
         mini.append(np.stack([x, y], 1)); mini_off.append(mini_off[-1] + nm)
         bid.append(int(rng.integers(0, 1 << 10)) | (int(rng.integers(0, 2)) << 31)); qlen.append(30100)
     mini = np.concatenate(mini)
-    fpga.load_index(blobs)
-    fpga.lib().fpga_set_params(500, 0, 25, 40, flag, max_occ)
-    exp = [fpga.collect_seeds(bid[r], qlen[r], mini[mini_off[r]:mini_off[r + 1]]) for r in range(n_reads)]
-    fpga.lib().fpga_finalize()
+    with ol.SeedIndex(blobs) as oix:
+        exp = [oix.collect_seeds(flag, max_occ, bid[r], qlen[r], mini[mini_off[r]:mini_off[r + 1]]) for r in range(n_reads)]
     with chaindp.Device(0, max_anchors=1 << 21, max_reads=64) as d:
         ix = d.load_index(blobs)
         import time
@@ -184,7 +181,7 @@ def test_gpu_seed_collection_against_host_statement_on_synthetic_images(seed, ma
     """Random index images and minimizer lists with many repeated minimizers (equal x in the anchors) and reads of a few
     hundred to > 200 k anchors: every sort path (bitonic, the reference's procedure in LDS with 32 / 4 bucket tables, and for
     reads beyond the LDS sort the top levels by k_seed_sort_huge with digits in LDS or, past ~150 k anchors, in global
-    memory).  Expected values come from the host statement (csrc/seed_collect.cpp), itself pinned against the reference
+    memory).  Expected values come from the oracle's restatement (oracle/seed_oracle.cpp), itself pinned against the reference
     on the CPU tier."""
     _synthetic_case(seed, max_cnt, n_mini, rep_pct)
 
