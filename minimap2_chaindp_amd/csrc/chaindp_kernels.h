@@ -117,9 +117,9 @@ hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag
                                    const int64_t *d_mini_off, const void *d_mini, const uint32_t *d_bid, const int32_t *d_qlen, SeedScratch sc,
                                    void *d_unsorted, void *d_a, const int64_t *d_off, unsigned long long *d_mini_pos, int max_n, int max_n2,
                                    int lab_cap, int64_t total);   // lab_cap: LDS bytes for digits in k_seed_sort_huge; total = d_off[n_reads]
-// LDS bytes of the per-read sort for reads of up to max_n anchors with `workers` bucket tables and `coop` wave-wide
-// histograms; the host picks the largest max_n (<= 8192; 32 workers, 8 histograms) and max_n2 (4 workers, 2 histograms)
-// that fit the device's LDS per workgroup
+// LDS bytes of the per-read sort for reads of up to max_n anchors in its first (workers = 32: sixteen waves with bucket
+// tables, 1024 queue slots for small ranges) or second configuration (workers = 4: four waves, 256 slots); coop is unused.
+// The host picks the largest max_n (<= 8192) and max_n2 that fit the device's LDS per workgroup.
 size_t seed_sort_lds_bytes(int max_n, int workers, int coop);
 
 // zero-copy movement between device-visible (pinned) host buffers and HBM: chaindp_io.hip

@@ -10,7 +10,7 @@
 //                  generation order, and its mini_pos entry
 //   k_seed_reads   wave per read: anchor / mini_pos offsets of the read and rep_len (the interval merge of
 //                  map.c:127-133, one term per skipped minimizer)
-//   k_seed_sort    wave per read, in LDS: the order radix_sort_128x (ksort.h:101-151) gives equal x is input to the
+//   k_seed_sort    workgroup per read, in LDS: the order radix_sort_128x (ksort.h:101-151) gives equal x is input to the
 //                  chaining DP, so a read with equal keys is sorted by the reference's procedure step by step; a
 //                  read without (the common case) by a bitonic network.
 //   k_seed_sort_huge  workgroup per read too large for LDS: top levels in global memory, buckets back to k_seed_sort
@@ -450,8 +450,8 @@ __device__ __forceinline__ void seed_isort(uint64_t *key, uint16_t *idx, int beg
 	}
 }
 
-// takes the reads (and work items) of up to max_n2 anchors: with 32 bucket tables and 8 wave-wide histograms up to max_n
-// anchors, with 4 and 2 above (the LDS layout is chosen per read; the launch reserves the larger of the two)
+// takes the reads (and work items) of up to max_n2 anchors: sixteen waves with bucket tables up to max_n anchors, four
+// above (the LDS layout is chosen per read; the launch reserves the larger of the two)
 #define SEED_TPB 1024
 // waves that have bucket tables (and so take large ranges): all sixteen for reads of the first configuration, four for the second
 __host__ __device__ inline int seed_table_waves(int workers) { return workers >= 32 ? SEED_TPB / 64 : 4; }
