@@ -6,8 +6,8 @@
 //                 first anchor and the read's hash), and the reference's radix_sort_128x of those keys -- its
 //                 insertion sort (stable: a rank by key and index, one lane per chain) for up to 64 chains, its
 //                 procedure step by step (chaindp_rsort.h) by one lane above
-//   k_regs_fill   wave per read, lane per hit: the record of hit.c:74-86 from the reversed key order, coordinates from
-//                 the chain's first and last anchor, mlen / blen by a walk over its anchors
+//   k_regs_fill   wave per read, one hit at a time: the record of hit.c:74-86 from the reversed key order, coordinates
+//                 from the chain's first and last anchor, mlen / blen as a sum over its anchors (a lane per anchor)
 //   k_regs_div    thread per hit: esterr.c:42-62 (binary search of the chain's first minimizer in mini_pos, a linear
 //                 match of the following ones, logf of the ratio)
 #include <hip/hip_runtime.h>
@@ -84,21 +84,22 @@ __global__ __launch_bounds__(256) void k_regs_fill(int64_t n_reads, const int64_
 	const int n_u = (int)(chains_off[r + 1] - c0);
 	const ulonglong2 *a = b + b_off[r];
 	const int ql = qlen[r];
-	for (int i = lane; i < n_u; i += 64) {
+	for (int i = 0; i < n_u; ++i) {                                         // the wave takes the read's hits one at a time, its lanes the anchors
 		const ulonglong2 zi = z[c0 + (n_u - 1 - i)];                        // hit.c:70-71: larger score first
 		const int cnt = (int)(int32_t)zi.y, as = (int)(zi.y >> 32), score = (int)(zi.x >> 32);
 		const ulonglong2 f = a[as], l = a[as + cnt - 1];
 		const int q_span = (int)(f.y >> 32 & 0xff), rev = (int)(f.x >> 63);
-		int mlen = q_span, blen = q_span;                                   // hit.c:8-22
-		ulonglong2 prev = f;
-		for (int k = as + 1; k < as + cnt; ++k) {
-			const ulonglong2 cur = a[k];
+		int mlen = 0, blen = 0;                                             // hit.c:8-22, one term per anchor after the first
+		for (int k = as + 1 + lane; k < as + cnt; k += 64) {
+			const ulonglong2 cur = a[k], prev = a[k - 1];
 			const int span = (int)(cur.y >> 32 & 0xff);
 			const int tl = (int)(int32_t)cur.x - (int)(int32_t)prev.x, qd = (int)(int32_t)cur.y - (int)(int32_t)prev.y;
 			blen += tl > qd ? tl : qd;
 			mlen += tl > span && qd > span ? span : tl < qd ? tl : qd;
-			prev = cur;
 		}
+		for (int d = 32; d > 0; d >>= 1) { mlen += __shfl_xor(mlen, d); blen += __shfl_xor(blen, d); }
+		mlen += q_span; blen += q_span;
+		if (lane != 0) continue;
 		int32_t *o = regs + (c0 + i) * 20;                                  // mm_reg1_t, minimap.h:100-115 (80 B)
 		o[0] = i; o[1] = cnt; o[2] = (int32_t)(f.x << 1 >> 33); o[3] = score;
 		if (!rev) { o[4] = (int32_t)f.y + 1 - q_span; o[5] = (int32_t)l.y + 1; }                       // hit.c:32-34
