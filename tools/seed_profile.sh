@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 run() { # name, env...
   name=$1; shift
-  ( export "$@"; rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/sp_$name -- python3 $R/tools/seed_scale_run.py 3 ) > $R/gpurun_out/sp_$name.log 2>&1
+  ( export "$@"; rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/sp_$name -- python3 $R/tools/seed_scale_run.py 3 ${MULT:-1} ) > $R/gpurun_out/sp_$name.log 2>&1
   tail -1 $R/gpurun_out/sp_$name.log
   f=$(find $R/gpurun_out/sp_$name -name '*kernel_stats.csv' | sort | tail -1)
   python3 - "$f" <<'PY'

@@ -13,13 +13,18 @@ from minimap2_chaindp_amd import chaindp  # noqa: E402
 
 g = np.load(os.path.join(ROOT, "tests", "golden", "_big", "big_avaont.npz"), allow_pickle=False)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-with chaindp.Device(0, max_anchors=1 << 23, max_reads=1 << 12) as d:
+mult = int(sys.argv[2]) if len(sys.argv) > 2 else 1              # the batch repeated `mult` times over (a larger batch of the same reads)
+mini_off = np.concatenate([[0], np.cumsum(np.tile(np.diff(g["mini_off"]), mult))]).astype(np.int64)
+mini, bid, qlen = np.tile(g["mini"], (mult, 1)), np.tile(g["bid"], mult), np.tile(g["qlen"], mult)
+with chaindp.Device(0, max_anchors=(1 << 23) * mult, max_reads=(1 << 12) * mult) as d:
     ix = d.load_index([g["img_B"], g["img_H"], g["img_V"], g["img_P"]])
     for _ in range(reps):
         t0 = time.time()
-        off, a, rep_len, mpo, mp = d.collect_seeds(ix, int(g["flag"]), int(g["mid_occ"]), g["mini_off"], g["mini"], g["bid"], g["qlen"])
+        off, a, rep_len, mpo, mp = d.collect_seeds(ix, int(g["flag"]), int(g["mid_occ"]), mini_off, mini, bid, qlen)
         dt = time.time() - t0
-    ok = np.array_equal(off, g["a_off"]) and np.array_equal(a, g["anchors"]) and np.array_equal(rep_len, g["rep_len"]) and np.array_equal(mp, g["mini_pos"])
+    n1 = len(g["anchors"])
+    ok = (np.array_equal(np.diff(off), np.tile(np.diff(g["a_off"]), mult)) and all(np.array_equal(a[k * n1:(k + 1) * n1], g["anchors"]) for k in range(mult))
+          and np.array_equal(rep_len, np.tile(g["rep_len"], mult)) and np.array_equal(mp, np.tile(g["mini_pos"], mult)))
     n = np.diff(off)
     print(f"{len(a)} anchors, {len(n)} reads (max {n.max()}), {dt * 1e3:.1f} ms with transfers, identical to the reference: {ok}")
     sys.exit(0 if ok else 1)
