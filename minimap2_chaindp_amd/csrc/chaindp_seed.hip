@@ -105,15 +105,29 @@ __device__ __forceinline__ bool seed_skip(int flag, uint64_t r, uint32_t q_pos, 
 	return false;
 }
 
-// largest r in [0, n_reads) with mini_off[r] <= i
-__device__ __forceinline__ int64_t seed_read_of(const int64_t *__restrict__ mini_off, int64_t n_reads, int64_t i)
+// largest r in [lo, hi] with mini_off[r] <= i (the answer is known to lie there)
+__device__ __forceinline__ int64_t seed_read_between(const int64_t *__restrict__ mini_off, int64_t lo, int64_t hi, int64_t i)
 {
-	int64_t lo = 0, hi = n_reads - 1;
 	while (lo < hi) {
 		const int64_t mid = (lo + hi + 1) >> 1;
 		if (mini_off[mid] <= i) lo = mid; else hi = mid - 1;
 	}
 	return lo;
+}
+
+// The read of minimizer i, for a workgroup of 256 consecutive minimizers: one thread searches all reads for the
+// workgroup's first and last minimizer, the others only between those two (a workgroup spans one or two reads, so
+// the thirteen dependent loads of a full search become none or one).  Every thread of the workgroup must call it.
+__device__ __forceinline__ int64_t seed_read_of_block(const int64_t *__restrict__ mini_off, int64_t n_reads, int64_t n_mini, int64_t i)
+{
+	__shared__ int64_t s_first, s_last;
+	if (threadIdx.x == 0) {
+		const int64_t i0 = (int64_t)blockIdx.x * blockDim.x, i1 = i0 + blockDim.x - 1 < n_mini - 1 ? i0 + blockDim.x - 1 : n_mini - 1;
+		s_first = seed_read_between(mini_off, 0, n_reads - 1, i0);
+		s_last = seed_read_between(mini_off, s_first, n_reads - 1, i1);
+	}
+	__syncthreads();
+	return seed_read_between(mini_off, s_first, s_last, i < n_mini ? i : n_mini - 1);
 }
 
 // per minimizer: mstate = hits (low 32 bits) | used << 32 | tandem << 33; src = where its hits are
@@ -124,9 +138,9 @@ __global__ __launch_bounds__(256) void k_seed_probe(SeedIndex ix, int flag, int 
                                                     unsigned long long *__restrict__ mstate)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t r = seed_read_of_block(mini_off, n_reads, n_mini, i);
 	if (i >= n_mini) return;
 	const ulonglong2 p = mini[i];
-	const int64_t r = seed_read_of(mini_off, n_reads, i);
 	int t;
 	const uint64_t where = seed_lookup(ix, p.x >> 8, &t);
 	unsigned long long k = 0, st = 0;
@@ -148,6 +162,7 @@ __global__ __launch_bounds__(256) void k_seed_expand(SeedIndex ix, int flag, int
                                                      ulonglong2 *__restrict__ a, unsigned long long *__restrict__ mini_pos)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t r = seed_read_of_block(mini_off, n_reads, n_mini, i);
 	if (i >= n_mini) return;
 	const unsigned long long st = mstate[i];
 	if (!(st >> 32 & 1)) return;
@@ -156,7 +171,6 @@ __global__ __launch_bounds__(256) void k_seed_expand(SeedIndex ix, int flag, int
 	mini_pos[used_pos[i]] = (unsigned long long)q_span << 32 | q_pos >> 1;               // map.c:141
 	const int t = (int)(uint32_t)st;
 	if (t == 0) return;
-	const int64_t r = seed_read_of(mini_off, n_reads, i);
 	const uint32_t b = bid[r], ql = (uint32_t)qlen[r];
 	const uint64_t seg = (uint64_t)((uint32_t)(p.y >> 32) & 0x7fffffffu) << SEED_SEG_SHIFT;
 	const uint64_t extra = seg | ((st >> 33 & 1) ? SEED_TANDEM_BIT : 0);
