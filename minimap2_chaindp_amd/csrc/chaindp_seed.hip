@@ -439,8 +439,8 @@ __global__ __launch_bounds__(256) void k_seed_sort_huge(int64_t n_reads, int min
 // waves, in LDS, on (key, original index) pairs.  A read whose keys all differ -- almost every read -- has a unique
 // sorted order and is done by a bitonic network.  Otherwise the reference's procedure is followed level by level:
 // ranges of more than 64 anchors go to the waves one at a time (digit counts by the wave, the bucket permutation
-// replayed over the digits by one lane, keys and indices moved by the wave), ranges of up to 64 are insertion-sorted
-// one per thread, and a level on which every key of a range has the same digit is skipped (the reference's pass
+// replayed over the digits by one lane, keys and indices moved by the wave), ranges of up to 64 are sorted a wave each
+// (the insertion sort is stable: a rank by key and place), and a level on which every key of a range has the same digit is skipped (the reference's pass
 // over it moves nothing).  Positions are 16-bit: a read here has at most max_n2 <= 65535 anchors.
 // LDS: keys[n] u64 | idx[n] u16 | W x (head, tail, start)[256] u16 | W x counts[256] u32 | two queues of ranges |
 // 4 counters | digits[n] u8, with n = max_n (<= 8192, W = 16 waves with tables, 1024 queue slots for small ranges) or
@@ -554,9 +554,17 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 			int *ncnt = qn + 2 * (which ^ 1);
 			const int n_big = qn[2 * which], n_small = min(qn[2 * which + 1], q_slots - q_big);
 			if (n_big + n_small == 0) break;
-			for (int w = lane; w < n_small; w += SEED_TPB) {                         // ksort.h:148, a thread per small range
-				const SeedRange rg = cur[q_big + w];
-				seed_isort(key, idx, rg.beg, rg.end);
+			for (int w = wave; w < n_small; w += SEED_TPB / 64) {                    // ksort.h:148, a wave per small range: the insertion sort of
+				const SeedRange rg = cur[q_big + w];                                // ksort.h:107-117 is stable, i.e. a rank by (key, place), a lane per anchor
+				const int len = rg.end - rg.beg;
+				const uint64_t k = wl < len ? key[rg.beg + wl] : ~0ull;
+				const uint16_t ix = wl < len ? idx[rg.beg + wl] : (uint16_t)0;
+				int rank = 0;
+				for (int j = 0; j < len; ++j) {
+					const uint64_t kj = readlane_u64(k, j);
+					rank += (kj < k) | (kj == k & j < wl);
+				}
+				if (wl < len) { key[rg.beg + rank] = k; idx[rg.beg + rank] = ix; }
 			}
 			for (int w = wave; w < n_big && wave < n_tab; w += n_tab) {              // a wave per large range
 				const SeedRange rg = cur[w];
