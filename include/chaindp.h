@@ -181,6 +181,36 @@ int chaindp_download_anchors(chaindp_ctx_t *ctx, chaindp_anchor_t *a);      /* t
 void *chaindp_host_alloc(size_t bytes);
 void chaindp_host_free(void *p);
 
+/* ---- streaming pipeline ("H2D + kernels + D2H"; 8e: 2-3 streams per device) -------------------------
+ * What the reference's driver did behind fpga_writebuf_submit / fpga_get_retbuf (fpga_chaindp.c:102-159,228-266):
+ * batches stream through the device while the host keeps producing.  A pipe owns `depth` contexts (each with its own
+ * stream and HBM buffers for max_anchors / max_reads) and `depth` pinned result buffers; chaindp_pipe_submit enqueues
+ * H2D of the batch, prepass + chain DP + compaction on the next free slot and returns at once, so that with depth >= 3
+ * the upload of batch n+1, the kernels of batch n and the download of batch n-1 overlap (the copy engines and the
+ * shader array are independent).  Batches complete in submission order.
+ *   off / a / n_segs_per_read as in chaindp_upload; they must stay valid until the batch has been waited for, and
+ *   the copies are asynchronous only if they are pinned memory (chaindp_host_alloc) -- pageable memory is staged by
+ *   the runtime, which serialises the pipe.
+ *   chaindp_pipe_wait blocks for the OLDEST submitted batch, downloads exactly its new_seed[] records and
+ *   describes them in *res (pinned, owned by the pipe, valid until chaindp_pipe_release, which frees the slot).
+ *   Returns CHAINDP_ERR_BUSY from submit when every slot is in flight, from wait when nothing is. */
+#define CHAINDP_ERR_BUSY     (-5)
+typedef struct chaindp_pipe chaindp_pipe_t;
+typedef struct {
+	int64_t tag;                     /* the caller's tag of the batch */
+	int64_t n_reads, n_anchors;      /* what was submitted */
+	int64_t n_seeds;                 /* seeds_off[n_reads] */
+	const int64_t *seeds_off;        /* [n_reads + 1] */
+	const chaindp_seed_t *seeds;     /* [n_seeds], new_seed[] of every read, chain.c:286-317 */
+} chaindp_pipe_result_t;
+chaindp_pipe_t *chaindp_pipe_create(int device, int depth, int64_t max_anchors, int64_t max_reads);
+void chaindp_pipe_destroy(chaindp_pipe_t *pipe);
+int chaindp_pipe_submit(chaindp_pipe_t *pipe, const chaindp_params_t *par, int64_t n_reads, const int64_t *off,
+                        const chaindp_anchor_t *a, const int32_t *n_segs_per_read, int64_t tag);
+int chaindp_pipe_wait(chaindp_pipe_t *pipe, chaindp_pipe_result_t *res);
+int chaindp_pipe_release(chaindp_pipe_t *pipe);
+const char *chaindp_pipe_last_error(const chaindp_pipe_t *pipe);
+
 /* ---- device-pointer path (inputs and outputs already in HBM) ---------------------------
  * All pointers are device addresses on ctx's GPU; stream is a hipStream_t passed as
  * void* (NULL = the context's own stream).  d_off int64[n_reads+1], d_a anchors,

@@ -26,6 +26,8 @@ ABI_SYMBOLS = (
     "chaindp_get_stats", "chaindp_set_ring", "chaindp_run_full", "chaindp_set_variant", "chaindp_upload_gather_ex", "chaindp_scatter_seeds", "chaindp_backtrack",
     "chaindp_index_create", "chaindp_index_destroy", "chaindp_collect_seeds", "chaindp_download_mini_pos", "chaindp_download_anchors", "chaindp_collect_seeds_gather", "chaindp_scatter_mini_pos",
     "chaindp_gen_regs", "chaindp_est_err",
+    "chaindp_pipe_create", "chaindp_pipe_destroy", "chaindp_pipe_submit", "chaindp_pipe_wait", "chaindp_pipe_release",
+    "chaindp_pipe_last_error",
 )
 
 # chaindp_reg_t == mm_reg1_t (minimap.h:100-115), 80 bytes; `bits` is the bit-field word (rev = bit 10)
@@ -89,6 +91,15 @@ def lib():
         L.chaindp_scatter_seeds.argtypes = [vp, i64, vp]
         L.chaindp_device_count.argtypes = []
         L.chaindp_download_anchors.argtypes = [vp, vp]
+        L.chaindp_pipe_create.restype = vp
+        L.chaindp_pipe_create.argtypes = [i32, i32, i64, i64]
+        L.chaindp_pipe_destroy.restype = None
+        L.chaindp_pipe_destroy.argtypes = [vp]
+        L.chaindp_pipe_submit.argtypes = [vp, P, i64, vp, vp, vp, i64]
+        L.chaindp_pipe_wait.argtypes = [vp, vp]
+        L.chaindp_pipe_release.argtypes = [vp]
+        L.chaindp_pipe_last_error.restype = C.c_char_p
+        L.chaindp_pipe_last_error.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -265,7 +276,9 @@ class Device:
         self._check(self._lib.chaindp_set_ring(self._ctx, ring))
 
     def set_variant(self, force_general):
-        self._check(self._lib.chaindp_set_variant(self._ctx, int(bool(force_general))))
+        """0 / False: two units per wave (k_chain_twin) + one per wave for what it hands over; 1 / True: everything through the
+        general variant of k_chain_units; 2: k_chain_units only (table-driven where it applies)."""
+        self._check(self._lib.chaindp_set_variant(self._ctx, int(force_general)))
 
     # -- measurement
     def set_profiling(self, on=True):
@@ -278,7 +291,97 @@ class Device:
         self._check(self._lib.chaindp_get_kernel_ms(self._ctx, ms, n, int(reset)))
         return {k: (ms[i], n[i]) for i, k in enumerate(("prepass", "chain_dp", "compact", "backtrack"))}
 
+    def leftover_units(self):
+        """Units the two-per-wave kernel handed over to the one-per-wave kernel in the last run (test / tuning hook)."""
+        self._lib.chaindp_debug_leftover.restype = C.c_int64
+        self._lib.chaindp_debug_leftover.argtypes = [C.c_void_p]
+        return int(self._lib.chaindp_debug_leftover(self._ctx))
+
     def stats(self):
         st = (C.c_int64 * 4)()
         self._check(self._lib.chaindp_get_stats(self._ctx, st))
         return dict(units=st[0], singletons=st[1], anchors=st[2], reads=st[3])
+
+
+class PinnedArray:
+    """A numpy view of pinned (DMA-able) host memory from chaindp_host_alloc; what makes Pipe's copies asynchronous."""
+
+    def __init__(self, shape, dtype):
+        self._lib = lib()
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        self._ptr = self._lib.chaindp_host_alloc(max(n, 1))
+        if not self._ptr:
+            raise ChainDPError("chaindp_host_alloc failed (no GPU runtime or out of pinned memory)")
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(n, 1)).from_address(self._ptr))[:n].view(dtype).reshape(shape)
+
+    def free(self):
+        if self._ptr:
+            self.array = None
+            self._lib.chaindp_host_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class _PipeResult(C.Structure):
+    _fields_ = [("tag", C.c_int64), ("n_reads", C.c_int64), ("n_anchors", C.c_int64), ("n_seeds", C.c_int64),
+                ("seeds_off", C.c_void_p), ("seeds", C.c_void_p)]
+
+
+class Pipe:
+    """chaindp_pipe_t: batches stream through `depth` contexts so that H2D(n+1), kernels(n) and D2H(n-1) overlap."""
+
+    def __init__(self, device=0, depth=3, max_anchors=1 << 24, max_reads=1 << 20):
+        self._lib = lib()
+        if self._lib.chaindp_device_count() <= 0:
+            raise ChainDPError("no HIP device visible: the chaining DP runs only on the GPU (no CPU fallback)")
+        self._p = self._lib.chaindp_pipe_create(device, depth, max_anchors, max_reads)
+        if not self._p:
+            raise ChainDPError((self._lib.chaindp_pipe_last_error(None) or b"").decode())
+        self.depth = depth
+        self._keep = {}
+
+    def close(self):
+        if self._p:
+            self._lib.chaindp_pipe_destroy(self._p)
+            self._p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ChainDPError(f"chaindp pipe error {rc}: {self._lib.chaindp_pipe_last_error(self._p).decode()}")
+
+    def submit(self, par, off, anchors, n_segs=None, tag=0):
+        """Asynchronous.  off / anchors / n_segs must stay alive (they are kept referenced here) until wait() returns the batch."""
+        off, anchors, ns = Device._prep(off, anchors, n_segs)
+        rc = self._lib.chaindp_pipe_submit(self._p, C.byref(par), len(off) - 1, _ptr(off), _ptr(anchors), _ptr(ns), tag)
+        if rc == -5:
+            return False
+        self._check(rc)
+        self._keep[tag] = (off, anchors, ns)
+        return True
+
+    def wait(self, copy=True):
+        """Oldest batch: (tag, seeds_off, seeds).  With copy=False the arrays alias the pipe's pinned buffers and are valid
+        until release()."""
+        r = _PipeResult()
+        self._check(self._lib.chaindp_pipe_wait(self._p, C.byref(r)))
+        soff = np.ctypeslib.as_array((C.c_int64 * (r.n_reads + 1)).from_address(r.seeds_off))
+        seeds = np.ctypeslib.as_array((C.c_uint8 * max(r.n_seeds * 24, 1)).from_address(r.seeds))[:r.n_seeds * 24].view(SEED_DTYPE)
+        if copy:
+            soff, seeds = soff.copy(), seeds.copy()
+        self._keep.pop(r.tag, None)
+        return r.tag, soff, seeds
+
+    def release(self):
+        self._check(self._lib.chaindp_pipe_release(self._p))

@@ -26,7 +26,7 @@ struct chaindp_ctx {
 	int ring = 128;
 	// resident batch
 	int64_t n_reads = 0, total = 0, n_seeds = 0;
-	bool has_n_segs = false, ran = false;
+	bool has_n_segs = false, ran = false, compact_ready = false;
 	int64_t *d_off = nullptr;
 	void *d_a = nullptr;
 	int32_t *d_n_segs = nullptr;
@@ -36,6 +36,9 @@ struct chaindp_ctx {
 	uint32_t epoch = 0;
 	unsigned long long *d_sumq = nullptr;
 	Unit *d_units = nullptr;
+	Unit *d_left = nullptr;               // units the two-per-wave kernel hands over to k_chain_units
+	unsigned long long *d_left_cnt = nullptr;
+	int variant = 0;                      // 0: k_chain_twin + k_chain_units for the rest; 1: k_chain_units, general variant; 2: k_chain_units only
 	unsigned long long *d_counters = nullptr;
 	chaindp::PrepassScratch pre = {nullptr, nullptr, nullptr, nullptr, nullptr};
 	chaindp::CompactScratch cmp = {nullptr, nullptr, nullptr, nullptr};
@@ -126,7 +129,7 @@ extern "C" void chaindp_destroy(chaindp_ctx_t *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	for (auto &es : ctx->pending) for (int k = 0; k < es.n; ++k) (void)hipEventDestroy(es.e[k]);
 	void *bufs[] = {ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_sumq, ctx->d_units,
-	                ctx->d_counters, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->pre.units_tmp, ctx->pre.hist, ctx->pre.block_reads, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
+	                ctx->d_counters, ctx->d_left, ctx->d_left_cnt, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->pre.units_tmp, ctx->pre.hist, ctx->pre.block_reads, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
 	for (void *b : bufs) if (b) (void)hipFree(b);
 	for (void *b : ctx->bot_allocs) if (b) (void)hipFree(b);
 	void *sbufs[] = {ctx->seed.kept, ctx->seed.used, ctx->seed.src, ctx->seed.mstate, ctx->seed.tile_tmp, ctx->seed.totals, ctx->seed.stacks,
@@ -162,6 +165,8 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_sumq, nr * 8);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_units, (na / 2 + 1) * sizeof(Unit));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 2 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left, (na / 2 + 1) * sizeof(Unit));
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left_cnt, sizeof(unsigned long long));
 	size_t flags_bytes0 = 0, cblocks_bytes0 = 0;
 	chaindp::compact_scratch_bytes(ctx->cap_anchors, &flags_bytes0, &cblocks_bytes0);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_first_child, na * 4);
@@ -194,7 +199,9 @@ extern "C" int chaindp_set_ring(chaindp_ctx_t *ctx, int ring)
 extern "C" int chaindp_set_variant(chaindp_ctx_t *ctx, int force_general)
 {
 	if (!ctx) return CHAINDP_ERR_ARG;
-	ctx->use_lut = force_general == 0;
+	if (force_general < 0 || force_general > 2) { ctx->err = "variant must be 0 (two units per wave + the rest), 1 (general) or 2 (one unit per wave)"; return CHAINDP_ERR_ARG; }
+	ctx->use_lut = force_general != 1;
+	ctx->variant = force_general;
 	return CHAINDP_OK;
 }
 
@@ -247,8 +254,19 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		HIP_TRY(ctx, hipMemsetAsync(ctx->d_tg, 0, (size_t)ctx->cap_anchors * 8, st));
 		ctx->epoch = 1;
 	}
-	HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, total / 2, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_units,
-	                                   ctx->d_counters, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags));
+	if (ctx->variant == 0 && lut && d_n_segs == nullptr) {
+		// ordinary units two per wave; what that kernel hands over (and nothing else) goes through k_chain_units
+		HIP_TRY(ctx, hipMemsetAsync(ctx->d_left_cnt, 0, sizeof(unsigned long long), st));
+		HIP_TRY(ctx, chaindp::launch_chain_twin(st, q, total / 2, d_off, d_a, ctx->d_sumq, lut, lut_stride, ctx->d_units, ctx->d_counters,
+		                                        d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->d_left, (unsigned int*)ctx->d_left_cnt,
+		                                        getenv("CHAINDP_TWIN_FORCE_LEFT") != nullptr, total));
+		const int64_t left_grid = total / 2 < 32768 ? total / 2 : 32768;
+		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, left_grid, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_left,
+		                                   ctx->d_left_cnt, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
+		                                   ctx->d_units, ctx->d_counters));
+	} else
+		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, total / 2, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_units,
+		                                   ctx->d_counters, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags));
 	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[2], st)); ctx->pending.push_back(es); }
 	ctx->stats[2] = total; ctx->stats[3] = n_reads;
 	return CHAINDP_OK;
@@ -337,16 +355,26 @@ static int compact_launch(chaindp_ctx *ctx, const chaindp_params_t *par)
 	if (rc) return rc;
 	if (!ctx->ran) { ctx->err = "compaction before chaindp_run"; return CHAINDP_ERR_ARG; }
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
-	if (!ctx->d_id) {
+	if (!ctx->compact_ready) {
+		// first use: every buffer is allocated into a local and committed only when all of them exist, so that an
+		// out-of-memory here leaves the context as it was (the next call tries again) instead of half-initialised
 		const size_t na = (size_t)ctx->cap_anchors, nr = (size_t)ctx->cap_reads;
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_id, na * 4));
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_seeds_off, (nr + 1) * 8));
-		if (!ctx->d_seeds) HIP_TRY(ctx, hipMalloc(&ctx->d_seeds, na * sizeof(chaindp_seed_t)));   // (seed collection may have made it already)
 		size_t flags_bytes = 0, blocks_bytes = 0;
 		chaindp::compact_scratch_bytes(ctx->cap_anchors, &flags_bytes, &blocks_bytes);
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->cmp.block_cnt, blocks_bytes));
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->cmp.tile_tmp, blocks_bytes));
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->cmp.n_seeds, 8));
+		void *nb[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+		const size_t sz[6] = {na * 4, (nr + 1) * 8, ctx->d_seeds ? 0 : na * sizeof(chaindp_seed_t), blocks_bytes, blocks_bytes, 8};
+		hipError_t e = hipSuccess;
+		for (int k = 0; k < 6 && e == hipSuccess; ++k) if (sz[k]) e = hipMalloc(&nb[k], sz[k]);
+		if (e != hipSuccess) {
+			for (void *b : nb) if (b) (void)hipFree(b);
+			ctx->err = std::string("compaction buffers: ") + hipGetErrorString(e);
+			return CHAINDP_ERR_HIP;
+		}
+		ctx->d_id = (int32_t*)nb[0]; ctx->d_seeds_off = (int64_t*)nb[1];
+		if (nb[2]) ctx->d_seeds = nb[2];                        // (seed collection may have made it already)
+		ctx->cmp.block_cnt = (unsigned long long*)nb[3]; ctx->cmp.tile_tmp = (unsigned long long*)nb[4];
+		ctx->cmp.n_seeds = (unsigned long long*)nb[5];
+		ctx->compact_ready = true;
 	}
 	EventSet es; es.n = 0; es.slot0 = 2;
 	if (ctx->prof) {
@@ -531,6 +559,16 @@ extern "C" int chaindp_est_err(chaindp_ctx_t *ctx, const int64_t *regs_off, chai
 	if (match_tot) HIP_TRY(ctx, hipMemcpyAsync(match_tot, ctx->d_reg_counts, (size_t)n_regs * 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(ctx, hipStreamSynchronize(st));
 	return CHAINDP_OK;
+}
+
+// test hook (not in the public header): units the two-per-wave kernel handed over to k_chain_units in the last run
+extern "C" int64_t chaindp_debug_leftover(chaindp_ctx_t *ctx)
+{
+	if (!ctx || !ctx->d_left_cnt) return -1;
+	unsigned long long c = 0;
+	if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+	    hipMemcpy(&c, ctx->d_left_cnt, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	return (int64_t)(uint32_t)c;
 }
 
 // test hook (not in the public header): fills one of the backtrack allocations (in allocation order) with a byte
@@ -906,5 +944,140 @@ extern "C" int chaindp_download_anchors(chaindp_ctx_t *ctx, chaindp_anchor_t *a)
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	if (ctx->total) HIP_TRY(ctx, hipMemcpyAsync(a, ctx->d_a, (size_t)ctx->total * 16, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return CHAINDP_OK;
+}
+
+// ---- streaming pipeline (include/chaindp.h): depth contexts, each with its own stream, round robin
+
+struct PipeSlot {
+	chaindp_ctx *ctx = nullptr;
+	int64_t *h_seeds_off = nullptr;          // pinned
+	chaindp_seed_t *h_seeds = nullptr;       // pinned
+	unsigned long long *h_n_seeds = nullptr; // pinned
+	hipEvent_t done = nullptr;               // kernels + small downloads of the batch
+	int64_t tag = 0, n_reads = 0, total = 0;
+	int state = 0;                           // 0 free, 1 in flight, 2 waited (results in use)
+};
+
+struct chaindp_pipe {
+	int device = -1, depth = 0;
+	std::vector<PipeSlot> slots;
+	int head = 0, tail = 0, inflight = 0;    // tail: oldest submitted, head: next to submit
+	std::string err;
+};
+
+extern "C" const char *chaindp_pipe_last_error(const chaindp_pipe_t *pipe)
+{
+	return pipe ? pipe->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" void chaindp_pipe_destroy(chaindp_pipe_t *pipe)
+{
+	if (!pipe) return;
+	if (pipe->device >= 0) (void)hipSetDevice(pipe->device);
+	for (auto &sl : pipe->slots) {
+		if (sl.ctx && sl.ctx->stream) (void)hipStreamSynchronize(sl.ctx->stream);
+		if (sl.done) (void)hipEventDestroy(sl.done);
+		if (sl.h_seeds_off) (void)hipHostFree(sl.h_seeds_off);
+		if (sl.h_seeds) (void)hipHostFree(sl.h_seeds);
+		if (sl.h_n_seeds) (void)hipHostFree(sl.h_n_seeds);
+		if (sl.ctx) chaindp_destroy(sl.ctx);
+	}
+	delete pipe;
+}
+
+extern "C" chaindp_pipe_t *chaindp_pipe_create(int device, int depth, int64_t max_anchors, int64_t max_reads)
+{
+	g_create_error.clear();
+	if (depth < 1 || depth > 8) { g_create_error = "chaindp_pipe_create: depth must be 1..8"; return nullptr; }
+	chaindp_pipe *pipe = new chaindp_pipe();
+	pipe->device = device; pipe->depth = depth;
+	pipe->slots.resize((size_t)depth);
+	for (auto &sl : pipe->slots) {
+		sl.ctx = chaindp_create(device, max_anchors, max_reads);
+		if (!sl.ctx) { chaindp_pipe_destroy(pipe); return nullptr; }
+		const size_t na = (size_t)sl.ctx->cap_anchors, nr = (size_t)sl.ctx->cap_reads;
+		hipError_t e = hipHostMalloc((void**)&sl.h_seeds_off, (nr + 1) * 8, hipHostMallocDefault);
+		if (e == hipSuccess) e = hipHostMalloc((void**)&sl.h_seeds, na * sizeof(chaindp_seed_t), hipHostMallocDefault);
+		if (e == hipSuccess) e = hipHostMalloc((void**)&sl.h_n_seeds, 64, hipHostMallocDefault);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+		if (e != hipSuccess) {
+			g_create_error = std::string("chaindp_pipe_create: ") + hipGetErrorString(e);
+			chaindp_pipe_destroy(pipe);
+			return nullptr;
+		}
+	}
+	return pipe;
+}
+
+#define PIPE_TRY(pipe, call)                                                                       \
+	do {                                                                                           \
+		hipError_t e_ = (call);                                                                    \
+		if (e_ != hipSuccess) {                                                                    \
+			(pipe)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+			return CHAINDP_ERR_HIP;                                                                \
+		}                                                                                          \
+	} while (0)
+
+extern "C" int chaindp_pipe_submit(chaindp_pipe_t *pipe, const chaindp_params_t *par, int64_t n_reads, const int64_t *off,
+                                   const chaindp_anchor_t *a, const int32_t *n_segs_per_read, int64_t tag)
+{
+	if (!pipe) return CHAINDP_ERR_ARG;
+	if (pipe->inflight == pipe->depth) { pipe->err = "every slot of the pipe is in flight: wait for the oldest batch first"; return CHAINDP_ERR_BUSY; }
+	PipeSlot &sl = pipe->slots[(size_t)pipe->head];
+	chaindp_ctx *ctx = sl.ctx;
+	int rc = check_params(ctx, par);
+	if (rc) { pipe->err = ctx->err; return rc; }
+	if (n_reads < 0 || !off || (n_reads > 0 && off[0] != 0)) { pipe->err = "bad offsets"; return CHAINDP_ERR_ARG; }
+	const int64_t total = n_reads > 0 ? off[n_reads] : 0;
+	if (total < 0 || (total > 0 && !a)) { pipe->err = "bad anchors"; return CHAINDP_ERR_ARG; }
+	if (n_reads > ctx->cap_reads || total > ctx->cap_anchors) { pipe->err = "batch exceeds the capacity the pipe was created with"; return CHAINDP_ERR_CAPACITY; }
+	PIPE_TRY(pipe, hipSetDevice(pipe->device));
+	hipStream_t st = ctx->stream;
+	PIPE_TRY(pipe, hipMemcpyAsync(ctx->d_off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+	if (total) PIPE_TRY(pipe, hipMemcpyAsync(ctx->d_a, a, (size_t)total * 16, hipMemcpyHostToDevice, st));
+	ctx->has_n_segs = n_segs_per_read != nullptr;
+	if (n_segs_per_read && n_reads) PIPE_TRY(pipe, hipMemcpyAsync(ctx->d_n_segs, n_segs_per_read, (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
+	ctx->n_reads = n_reads; ctx->total = total; ctx->ran = false; ctx->bot_n_reads = -1; ctx->mp_resident = false;
+	rc = chaindp_run_full(ctx, par);
+	if (rc) { pipe->err = ctx->err; return rc; }
+	PIPE_TRY(pipe, hipMemcpyAsync(sl.h_seeds_off, ctx->d_seeds_off, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, st));
+	PIPE_TRY(pipe, hipMemcpyAsync(sl.h_n_seeds, ctx->cmp.n_seeds, 8, hipMemcpyDeviceToHost, st));
+	PIPE_TRY(pipe, hipEventRecord(sl.done, st));
+	sl.tag = tag; sl.n_reads = n_reads; sl.total = total; sl.state = 1;
+	pipe->head = (pipe->head + 1) % pipe->depth;
+	++pipe->inflight;
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_pipe_wait(chaindp_pipe_t *pipe, chaindp_pipe_result_t *res)
+{
+	if (!pipe || !res) return CHAINDP_ERR_ARG;
+	PipeSlot &sl = pipe->slots[(size_t)pipe->tail];
+	if (pipe->inflight == 0 || sl.state != 1) { pipe->err = sl.state == 2 ? "release the batch waited for first" : "nothing in flight"; return CHAINDP_ERR_BUSY; }
+	PIPE_TRY(pipe, hipSetDevice(pipe->device));
+	PIPE_TRY(pipe, hipEventSynchronize(sl.done));
+	// the record count is known now: download exactly the batch's new_seed[] (the other slots' uploads and kernels go on)
+	const int64_t m = sl.total > 0 && sl.n_reads > 0 ? (int64_t)(uint32_t)*sl.h_n_seeds : 0;
+	sl.ctx->n_seeds = m;
+	if (m > 0) {
+		PIPE_TRY(pipe, hipMemcpyAsync(sl.h_seeds, sl.ctx->d_seeds, (size_t)m * sizeof(chaindp_seed_t), hipMemcpyDeviceToHost, sl.ctx->stream));
+		PIPE_TRY(pipe, hipStreamSynchronize(sl.ctx->stream));
+	}
+	if (sl.n_reads == 0) sl.h_seeds_off[0] = 0;
+	res->tag = sl.tag; res->n_reads = sl.n_reads; res->n_anchors = sl.total; res->n_seeds = m;
+	res->seeds_off = sl.h_seeds_off; res->seeds = sl.h_seeds;
+	sl.state = 2;
+	return CHAINDP_OK;
+}
+
+extern "C" int chaindp_pipe_release(chaindp_pipe_t *pipe)
+{
+	if (!pipe) return CHAINDP_ERR_ARG;
+	PipeSlot &sl = pipe->slots[(size_t)pipe->tail];
+	if (sl.state != 2) { pipe->err = "no waited batch to release"; return CHAINDP_ERR_ARG; }
+	sl.state = 0;
+	pipe->tail = (pipe->tail + 1) % pipe->depth;
+	--pipe->inflight;
 	return CHAINDP_OK;
 }

@@ -42,13 +42,22 @@ hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, in
 // bw <= CHAINDP_LUT_MAX_BW.  d_lut == nullptr makes every unit take the general (f64) variant.
 #define CHAINDP_LUT_MAX_BW 4095
 hipError_t launch_lut(hipStream_t st, const Params &par, int64_t n_reads, const int64_t *d_off,
-                      const unsigned long long *d_sumq, int lut_stride, uint16_t *d_lut);
+                      unsigned long long *d_sumq, int lut_stride, uint16_t *d_lut);
 size_t chain_lds_bytes(int ring, int lut_stride);
 
 hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
                         const int32_t *d_n_segs, const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
                         const Unit *d_units, const unsigned long long *d_counters,
-                        int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags);
+                        int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags,
+                        const Unit *d_units_all = nullptr, const unsigned long long *d_counters_all = nullptr);
+
+// Two units per wave, 32 lanes each (chaindp_twin.hip): takes the ordinary units, appends the others (general-variant reads,
+// scans that reach beyond 64 predecessors) to d_left / *d_left_cnt (low 32 bits = count), which launch_chain then runs.
+hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
+                             const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride, const Unit *d_units,
+                             const unsigned long long *d_counters, int32_t *d_f, int32_t *d_p, int32_t *d_v,
+                             int32_t *d_first_child, uint8_t *d_flags, Unit *d_left, unsigned int *d_left_cnt, int force_left, int64_t total);
+size_t twin_lds_bytes();
 
 // exclusive scan of n uint64 items in place (d_tile_tmp: ceil(n/1024)+1 words), total to *d_total
 hipError_t launch_scan_u64(hipStream_t st, int64_t n, unsigned long long *d_data, unsigned long long *d_tile_tmp,

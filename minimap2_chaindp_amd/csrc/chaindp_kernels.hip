@@ -720,7 +720,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                     const Unit *__restrict__ units,
                                                     const unsigned long long *__restrict__ counters,
                                                     int32_t *f, int32_t *p, int32_t *v, unsigned long long *tg, uint32_t epoch,
-                                                    int32_t *first_child, uint8_t *flags)
+                                                    int32_t *first_child, uint8_t *flags,
+                                                    const Unit *__restrict__ units_all, const unsigned long long *__restrict__ counters_all)
 {
 	static_assert((RING & (RING - 1)) == 0 && RING >= 128, "RING must be a power of two >= 128");
 	extern __shared__ uint4 smem[];
@@ -743,7 +744,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 	const bool x32_ok = ((uint64_t)(int64_t)par.max_dist_x + 1) * (uint64_t)(RING + 1) < (1ull << 32);
 	const int lane = threadIdx.x;
 
-	const int64_t n_units = (int64_t)(uint32_t)counters[0];       // low word: units, high word: singletons (prepass)
+	int64_t n_units = (int64_t)(uint32_t)counters[0];             // low word: units, high word: singletons (prepass)
+	// launched on the list of units k_chain_twin handed over: a count of all ones there means "every unit of the batch,
+	// in the prepass' (longest first) order"
+	if (units_all && (uint32_t)counters[0] == 0xffffffffu) { units = units_all; n_units = (int64_t)(uint32_t)counters_all[0]; }
 	for (int64_t ub = blockIdx.x; ub < n_units; ub += gridDim.x) {
 		const Unit u = units[ub];
 		const int64_t rs = off[u.read], re = off[u.read + 1];
@@ -751,7 +755,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 		const int n_segs = n_segs_pr ? n_segs_pr[u.read] : par.n_segs;
 		c.base = u.start;
 		c.rel0 = (int)(u.start - rs);
-		c.avgd = (double)((float)(uint64_t)(sq & ~SUMQ_SEG_FLAG) / (float)(int64_t)(re - rs));   // chain.c:241: f32 divide of converted u64 and i64
+		c.avgd = (double)((float)(uint64_t)(sq & ~(SUMQ_SEG_FLAG | SUMQ_LUT16_FLAG)) / (float)(int64_t)(re - rs));   // chain.c:241: f32 divide of converted u64 and i64
 		c.seg_rule = n_segs > 1 && !par.is_cdna;                   // chain.c:261
 		const bool general = par.is_cdna || n_segs > 1 || (sq & SUMQ_SEG_FLAG) || lut == nullptr || !x32_ok
 		                     || par.max_dist_x < 1 || par.max_dist_y < 0;
@@ -782,7 +786,8 @@ size_t chain_lds_bytes(int ring, int lut_stride)
 hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
                         const int32_t *d_n_segs, const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
                         const Unit *d_units, const unsigned long long *d_counters,
-                        int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags)
+                        int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags,
+                        const Unit *d_units_all, const unsigned long long *d_counters_all)
 {
 	if (max_units <= 0) return hipSuccess;
 	// The number of units is only known on the device (counters[0]); the grid is sized for the upper
@@ -802,9 +807,9 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
 		if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
 	}
 	switch (ring) {
-	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags); break;
-	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags); break;
-	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags); break;
+	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all); break;
+	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all); break;
+	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all); break;
 	}
 	return hipGetLastError();
 }

@@ -232,18 +232,20 @@ __global__ __launch_bounds__(256) void k_unit_scatter(const unsigned long long *
 // so it is tabulated once per read (bw+1 entries, uint16) with exactly the
 // reference's f32/f64 operations, and the hot loop does an LDS lookup instead of f64 arithmetic.
 __global__ __launch_bounds__(256) void k_build_lut(Params par, int64_t n_reads, const int64_t *__restrict__ off,
-                                                   const unsigned long long *__restrict__ sumq, int lut_stride,
+                                                   unsigned long long *__restrict__ sumq, int lut_stride,
                                                    uint16_t *__restrict__ lut)
 {
 	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
 		const int64_t n = off[r + 1] - off[r];
 		if (n <= 0) continue;
-		const float avg = (float)(uint64_t)(sumq[r] & ~SUMQ_SEG_FLAG) / (float)n;   // chain.c:241
+		const float avg = (float)(uint64_t)(sumq[r] & ~(SUMQ_SEG_FLAG | SUMQ_LUT16_FLAG)) / (float)n;   // chain.c:241
 		const double avgd = (double)avg;
 		for (int dd = threadIdx.x; dd <= par.bw; dd += blockDim.x) {
 			const int lg = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
 			const int lin = (int)((double)dd * .01 * avgd);
 			lut[r * lut_stride + dd] = (uint16_t)(int16_t)(1 - (lin + (lg >> 1)));  // stored as 1 - cost (see fast_masks): |.| < 2^15 for bw <= 4095, q_span <= 255
+			// the cost grows with dd: the last entry tells whether the whole table fits a signed byte (k_chain_twin keeps it as bytes)
+			if (dd == par.bw && 1 - (lin + (lg >> 1)) < -128) atomicOr(&sumq[r], SUMQ_LUT16_FLAG);
 		}
 	}
 }
@@ -280,7 +282,7 @@ size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *bl
 	return *mask_bytes + 2 * *blocks_bytes;
 }
 hipError_t launch_lut(hipStream_t st, const Params &par, int64_t n_reads, const int64_t *d_off,
-                      const unsigned long long *d_sumq, int lut_stride, uint16_t *d_lut)
+                      unsigned long long *d_sumq, int lut_stride, uint16_t *d_lut)
 {
 	if (n_reads <= 0) return hipSuccess;
 	int64_t blocks = n_reads < 65536 ? n_reads : 65536;

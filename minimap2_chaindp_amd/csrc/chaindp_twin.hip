@@ -1,0 +1,609 @@
+// chaindp_twin.hip -- the chain DP kernel for ordinary long-read units: TWO units per wave64, one per 32-lane half.
+//
+// Why (measured on MI355X, tools/issue_calib.hip -> profiles/r02_issue_calib.json): the one-unit-per-wave kernel
+// (chaindp_kernels.hip) spends ~29 scalar and ~31 vector instructions per anchor.  The scalar unit is shared by the
+// CU's four SIMDs and issues ONE instruction per cycle per CU, so 29 of them cost each SIMD ~125 of its 140 cycles per
+// anchor; vector instructions that read an SGPR, have three register sources or use DPP issue at half rate (4.2
+// cycles instead of 2.4).  And the scan of an ava-ont anchor ends (max_skip + 1 marked predecessors, chain.c:277-279)
+// within 32 predecessors 99.99 % of the time (map-ont: 71 %, within 48: 99.9 %), so half of a 64-lane pass is wasted.
+// Hence: chunks of 32 predecessors, two independent units side by side in one wave, and everything that is uniform
+// per unit kept in VECTOR registers (replicated over the half's lanes) and updated by plain two-operand VALU
+// instructions; the scalar unit only combines 64-bit lane masks (both halves at once) and branches.
+//
+// What it computes is exactly run_unit_fast of chaindp_kernels.hip (reference chain.c:246-284 for reads with one
+// segment, not cDNA, bw <= 511), with the same four derivations on 32-lane chunks.  Units it
+// does not take -- general-variant reads, and any unit whose scan needs a predecessor older than its LDS ring (64
+// anchors) -- are appended to a leftover list and run by k_chain_units afterwards, from scratch.
+//
+// LDS per wave (dynamic segment, starts at byte 0; h = half):
+//   XY  [128 slots][2 halves] 8 B   x.lo+1, qpos+1 of anchor (slot = i & 127), written a whole tile at a time
+//   PF  [ 64 slots][2 halves] 8 B   4*p (unit-relative, -4 = none), f of anchor (slot = i & 63)
+//   MK  [2 halves][65 + pad] 4 B    marks by distance: word d-1 holds the scan tag of the anchor d behind; word 64 = sink
+//   V   [ 64 slots][2 halves] 4 B   v | "emitted at its own step" << 31
+//   CUR [2 halves][32] 16 B         the current tile's anchors as a pass wants them: x.lo, qpos, q_span - 1, q_span
+//   LUT [2 halves][512] int8        the read's table of 1 - cost (reads whose costs do not fit a byte go to k_chain_units)
+//   ST  [2 halves] 64 B             the half's cold state (TwinCold)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+#include "chaindp_kernels.h"
+#include "chaindp_wave.h"
+
+namespace chaindp {
+
+#define TW_XY 0u
+#define TW_PF 2048u
+#define TW_MK 3072u
+#define TW_MK_HALF 272u
+#define TW_V 3616u
+#define TW_CUR 4128u
+#define TW_CUR_HALF 512u
+#define TW_LUT 5152u
+#define TW_LUT_HALF 512u
+#define TW_ST 6176u
+#define TW_LDS_BYTES 6304u
+#define TW_RING 64                      // predecessors a scan can reach in this kernel (two chunks of 32)
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TW_LDS(T, a) ((__attribute__((address_space(3))) T*)(a))
+#else
+#define TW_LDS(T, a) ((T*)(uintptr_t)(a))          /* host pass of the single-source compile; never executed */
+#endif
+typedef uint32_t tw_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t tw_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ tw_u32x2 tw_ld64(uint32_t a) { return *TW_LDS(const tw_u32x2, a); }
+__device__ __forceinline__ int tw_ld32(uint32_t a) { return *TW_LDS(const int, a); }
+__device__ __forceinline__ int tw_ld_i8(uint32_t a) { return (int)*TW_LDS(const signed char, a); }
+__device__ __forceinline__ tw_u32x4 tw_ld128(uint32_t a) { return *TW_LDS(const tw_u32x4, a); }
+__device__ __forceinline__ void tw_st64(uint32_t a, uint32_t x, uint32_t y) { tw_u32x2 t; t.x = x; t.y = y; *TW_LDS(tw_u32x2, a) = t; }
+__device__ __forceinline__ void tw_st32(uint32_t a, int v) { *TW_LDS(int, a) = v; }
+__device__ __forceinline__ void tw_st8(uint32_t a, int v) { *TW_LDS(signed char, a) = (signed char)v; }
+__device__ __forceinline__ void tw_st128(uint32_t a, uint32_t x, uint32_t y, uint32_t z, uint32_t w) { tw_u32x4 t; t.x = x; t.y = y; t.z = z; t.w = w; *TW_LDS(tw_u32x4, a) = t; }
+
+// keeps a value in a vector register: the compiler would otherwise hold wave-uniform values in SGPRs and feed them
+// to VALU instructions as scalar operands, which halves their issue rate
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TW_VREG(x) asm volatile("" : "+v"(x))
+#else
+#define TW_VREG(x) ((void)(x))
+#endif
+
+// a lane mask is wave-uniform by construction; where the compiler's divergence analysis loses track of that (values merged
+// behind loops) this keeps it in scalar registers (folds away when it already is)
+#define TW_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+
+// exclusive prefix max over the 32 lanes of each half, floor 0 (scores are >= 0 where they matter): inclusive scan
+// inside the 16-lane rows (4 DPP steps), one-lane shift inside the rows, and for the upper row of each half the lower
+// row's total (row_bcast:15 into rows 1 and 3; harmless for the lanes that already hold a larger prefix)
+__device__ __forceinline__ int tw_excl_max32(int v)
+{
+	v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, true));
+	v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(2), 0xf, 0xf, true));
+	v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(4), 0xf, 0xf, true));
+	v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(8), 0xf, 0xf, true));
+	int e = __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, true);
+#if defined(__HIP_DEVICE_COMPILE__)
+	// rows 1 and 3: e = max(e, lane 15 of the row below); rows 0 and 2 keep e (one DPP instruction; the two s_nop cover the
+	// VALU-write -> DPP-read hazard on v and e whatever the scheduler puts in front)
+	asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(e) : "v"(v));
+#endif
+	return e;
+}
+// inclusive prefix min over the 32 lanes of each half (general walk)
+__device__ __forceinline__ int tw_incl_min32(int v)
+{
+	v = min(v, dpp_or_old<DPP_ROW_SHR(1), 0xf>(INT_MAX, v));
+	v = min(v, dpp_or_old<DPP_ROW_SHR(2), 0xf>(INT_MAX, v));
+	v = min(v, dpp_or_old<DPP_ROW_SHR(4), 0xf>(INT_MAX, v));
+	v = min(v, dpp_or_old<DPP_ROW_SHR(8), 0xf>(INT_MAX, v));
+	v = min(v, dpp_or_old<DPP_ROW_BCAST15, 0xa>(INT_MAX, v));
+	return v;
+}
+
+// bits of the 64-bit lane mask m below this lane, counted inside the lane's own half
+__device__ __forceinline__ int tw_below_in_half(uint64_t m, bool hi_half)
+{
+	const int lo = (int)__builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u);
+	const int hi = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), 0u);
+	return hi_half ? hi : lo;
+}
+
+// per half: mask of all 32 lanes if any bit of m is set in that half (four scalar instructions; written out because the
+// compiler turns the C form into 64-bit vector compares)
+__device__ __forceinline__ uint64_t tw_smear_halves(uint64_t m)
+{
+	uint32_t lo = 0, hi = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm("s_cmp_lg_u32 %2, 0\n\ts_cselect_b32 %0, -1, 0\n\ts_cmp_lg_u32 %3, 0\n\ts_cselect_b32 %1, -1, 0"
+	    : "=&s"(lo), "=&s"(hi) : "s"(TW_UNI((uint32_t)m)), "s"(TW_UNI((uint32_t)(m >> 32))) : "scc");
+#endif
+	return (uint64_t)hi << 32 | lo;
+}
+
+// per half: the highest set bit of m alone, or the half's lane 0 if m has none there (s_flbit gives -1 for 0, and a
+// shift only uses the low five bits of its count: 0x80000000 >> 31 = lane 0)
+__device__ __forceinline__ uint64_t tw_last_or_lane0(uint64_t m)
+{
+	uint32_t lo = 0, hi = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm("s_flbit_i32_b32 %0, %2\n\ts_flbit_i32_b32 %1, %3\n\ts_lshr_b32 %0, 0x80000000, %0\n\ts_lshr_b32 %1, 0x80000000, %1"
+	    : "=&s"(lo), "=&s"(hi) : "s"(TW_UNI((uint32_t)m)), "s"(TW_UNI((uint32_t)(m >> 32))));
+#endif
+	return (uint64_t)hi << 32 | lo;
+}
+
+// nonzero iff m has a set bit in BOTH halves (three scalar instructions with the compare the caller adds)
+__device__ __forceinline__ uint32_t tw_both_halves(uint64_t m)
+{
+	uint32_t t = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(t) : "s"(TW_UNI((uint32_t)m)), "s"(TW_UNI((uint32_t)(m >> 32))) : "scc");
+#endif
+	return t;
+}
+
+// |a - b| + c in one instruction
+__device__ __forceinline__ uint32_t tw_sad(uint32_t a, uint32_t b, uint32_t c)
+{
+	uint32_t d = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+#endif
+	return d;
+}
+
+// per half: bits of m below the half's lowest set bit of b (all of m where b has none)
+__device__ __forceinline__ uint64_t tw_below_first(uint64_t m, uint64_t b)
+{
+	const uint32_t blo = (uint32_t)b, bhi = (uint32_t)(b >> 32);
+	const uint32_t klo = blo ? (blo & (0u - blo)) - 1u : 0xffffffffu, khi = bhi ? (bhi & (0u - bhi)) - 1u : 0xffffffffu;
+	return m & ((uint64_t)khi << 32 | klo);
+}
+
+// lane masks straight from a vector compare (v_cmp_*_e64 into an SGPR pair, no bool in between)
+#define TW_ULT(a, b) __builtin_amdgcn_uicmp((unsigned)(a), (unsigned)(b), 36)
+#define TW_EQ(a, b)  __builtin_amdgcn_uicmp((unsigned)(a), (unsigned)(b), 32)
+#define TW_SGT(a, b) __builtin_amdgcn_sicmp((int)(a), (int)(b), 38)
+#define TW_SGE(a, b) __builtin_amdgcn_sicmp((int)(a), (int)(b), 39)
+#define TW_SEL(m, a, b) (__builtin_amdgcn_inverse_ballot_w64(m) ? (a) : (b))
+#define TW_HI31 0x8000000080000000ull
+
+struct TwinArgs {
+	Params par;
+	const int64_t *off;
+	const ulonglong2 *a;
+	const unsigned long long *sumq;
+	const uint16_t *lut;
+	int lut_stride;
+	const Unit *units;
+	const unsigned long long *counters;
+	int32_t *f, *p, *v;
+	int32_t *first_child;
+	uint8_t *flags;
+	Unit *left;                       // leftover list for k_chain_units
+	unsigned int *left_cnt;
+	int force_left;                   // test switch: hand every unit over
+	int64_t total;                    // anchors of the batch
+};
+
+// the state of a half that only the service path needs lives in LDS (TW_ST + 64 h), so that the pass loop carries
+// nothing but what a pass reads
+struct TwinCold {
+	int64_t next;                     // next unit of this half (grid-stride over pairs)
+	int64_t base;                     // global index of the unit's first anchor
+	uint64_t x_carry;                 // x of the previous tile's last anchor
+	int32_t rel0, room, read, tile0;  // unit start relative to its read; anchors the unit may have; its read; current tile's first anchor
+};
+
+// what a pass reads and writes, per half, replicated over the half's lanes
+struct TwinHot {
+	uint32_t S;                       // 16 * jtop + 8h, jtop = i - 1 - 32c: ring offset of lane 0's predecessor
+	uint32_t m4;                      // 4 * (i - 1) + mark base: mark distance base and the scan's tag
+	uint32_t j4;                      // 4 * jtop
+	uint32_t pc, pend;                // CUR entry of the current anchor; end of the tile's entries
+	// constant while a half is in its first chunk:
+	int maxf;                         // running max of the scan (chain.c:274) carried into a second chunk
+	uint32_t kb4;                     // 128 * c
+	int maxj4, nskip;                 // 4 * max_j (-4: none); n_skip carried into the chunk
+	int slow;                         // second chunks the unit has needed so far
+};
+
+template <bool SAMEGAP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_chain_twin(TwinArgs g)
+{
+	const int lane = threadIdx.x;
+	const bool hi_half = lane >= 32;
+	const int h = lane >> 5, hl = lane & 31;
+	const uint64_t my_half = hi_half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+
+	// ---- per-lane constants (vector registers on purpose, see TW_VREG)
+	uint32_t L16 = (uint32_t)hl << 4, L4 = (uint32_t)hl << 2;
+	const uint32_t mkbase = TW_MK + TW_MK_HALF * (uint32_t)h;      // this half's mark words
+	const uint32_t curbase = TW_CUR + TW_CUR_HALF * (uint32_t)h;   // this half's CUR entries
+	uint32_t c_mkbase = mkbase;
+	uint32_t c_far = mkbase + 256u;                                // its sink word
+	uint32_t c_own = mkbase + ((uint32_t)hl << 2);                 // lane's own mark word in chunk 0
+	uint32_t c_lut = TW_LUT + TW_LUT_HALF * (uint32_t)h;
+	uint32_t c_8h = (uint32_t)h << 3;
+	uint32_t c_M = (uint32_t)g.par.max_dist_x;
+	uint32_t c_bw = (uint32_t)g.par.bw;
+	uint32_t c_cbw = c_M - 1u > c_bw ? c_M - 1u - c_bw : 0u;
+	const uint32_t mdq = (uint32_t)(g.par.max_dist_x < g.par.max_dist_y ? g.par.max_dist_x : g.par.max_dist_y);
+	uint32_t c_dqoff = c_M - mdq;
+	int c_ms = g.par.max_skip;
+	int c_min = INT_MIN;
+	int c_Mout = hl == 31 ? g.par.max_dist_x : INT_MAX;            // window test that only the half's last lane can fail
+	uint32_t c_bwl = c_bw + c_lut;                                 // table address of the last entry
+	uint32_t c_cbwl = c_cbw - c_lut;                               // (dd + c_lut) + this = dd + c_cbw
+	TW_VREG(L16); TW_VREG(L4); TW_VREG(c_mkbase); TW_VREG(c_far); TW_VREG(c_own); TW_VREG(c_lut); TW_VREG(c_8h); TW_VREG(c_M); TW_VREG(c_bw);
+	TW_VREG(c_cbw); TW_VREG(c_dqoff); TW_VREG(c_ms); TW_VREG(c_min); TW_VREG(c_Mout); TW_VREG(c_bwl); TW_VREG(c_cbwl);
+
+	const uint64_t maxx = (uint64_t)(int64_t)g.par.max_dist_x;
+	const int64_t n_units = (int64_t)(uint32_t)g.counters[0];
+	// the kernel's 32-bit differences (and the signed window test) are exact while 129 * (max_dist_x + 1) < 2^31
+	// Units of a few thousand anchors (map-ont shape) are few and each is a long serial chain: two of them side by side gain
+	// nothing and their scans need the second chunk for one anchor in three.  Such batches go to k_chain_units as a whole.
+	const int64_t n_single = (int64_t)(g.counters[0] >> 32);
+	const bool short_units = (g.total - n_single) <= 512 * n_units;
+	if (!short_units) {                                            // (uniform: every block leaves; one of them says so)
+		if (blockIdx.x == 0 && lane == 0) *g.left_cnt = 0xffffffffu;
+		return;
+	}
+	const bool params_ok = g.lut != nullptr && !g.par.is_cdna && g.par.max_dist_x >= 1 && g.par.max_dist_y >= 0 &&
+	                       ((uint64_t)(int64_t)g.par.max_dist_x + 1) * 129ull < (1ull << 31) && g.par.bw + 1 <= (int)TW_LUT_HALF && !g.force_left;
+
+	TwinHot u;
+	u.S = 0; u.m4 = 0; u.j4 = 0; u.pc = curbase; u.pend = curbase; u.maxf = 0; u.kb4 = 0; u.maxj4 = -4; u.nskip = 0; u.slow = 0;
+	uint64_t live_m = ~0ull;                                       // halves that still have (or may get) work
+	uint64_t contm = 0;                                            // halves that are in their second (= last) chunk
+	const uint32_t st_addr = TW_ST + 64u * (uint32_t)h;
+#define TW_COLD (*TW_LDS(TwinCold, st_addr))
+	if (hl == 0) {
+		TwinCold c0;
+		c0.next = 2 * (int64_t)blockIdx.x + h; c0.base = 0; c0.x_carry = 0; c0.rel0 = 0; c0.room = 0; c0.read = 0; c0.tile0 = -32;
+		TW_COLD = c0;
+	}
+	wave_mem_fence();
+
+	// One service round: every lane of the `svc` halves (a) flushes its finished tile, (b) if the unit is finished picks
+	// the half's next unit and prepares its LDS, (c) loads the next tile and publishes it to the rings, (d) makes the
+	// tile's first anchor current.  Divergent (per half) on purpose; executed once per 32 anchors and half.
+	auto service = [&](uint64_t svc) {
+		const bool mine = (svc & my_half) != 0;
+		wave_mem_fence();
+		TwinCold c = TW_COLD;
+		bool live = true;
+		int cnt_prev = (int)(u.pend - curbase) >> 4;                     // anchors of the tile that has just been scored
+		// ---- (a) flush
+		if (mine && cnt_prev > 0) {
+			const int i_lane = c.tile0 + hl;                             // this lane's anchor of the finished tile
+			const bool have = hl < cnt_prev;
+			const int64_t gi = c.base + i_lane;
+			int fi = 0, p4 = -4;
+			if (have) {
+				const tw_u32x2 pf = tw_ld64((((uint32_t)i_lane & 63u) << 4 | c_8h) + TW_PF);
+				p4 = (int)pf.x; fi = (int)pf.y;
+			}
+			const int pi = p4 >> 2;                                      // unit-relative predecessor, -1 = none
+			int val = fi, ptr = have ? pi : -1;
+			const bool ext = ptr >= 0 && ptr < c.tile0;                  // predecessor in an earlier tile: its v is final, in the V ring
+			int vext = 0;
+			if (ext) {
+				vext = tw_ld32((((uint32_t)ptr & 63u) << 3 | (uint32_t)h << 2) + TW_V);
+				val = max(val, vext & 0x7fffffff);
+				ptr = -1;
+			}
+			const bool ext_self = ext && vext < 0;                       // (bit 31 of a V entry: the anchor was emitted at its own step)
+			for (int r = 0; r < 5; ++r) {                                // v[i] = max(f[i], v[p[i]]) (chain.c:284) by pointer doubling over the tile
+				if (__builtin_amdgcn_ballot_w64(ptr >= c.tile0) == 0) break;
+				const int src = ((ptr >= c.tile0 ? ptr - c.tile0 : hl) + (h << 5)) << 2;
+				const int pv = __builtin_amdgcn_ds_bpermute(src, val);
+				const int pp = __builtin_amdgcn_ds_bpermute(src, ptr);
+				if (ptr >= c.tile0) { val = max(val, pv); ptr = pp; }
+			}
+			const bool self = val >= g.par.min_sc || pi >= 0;            // emitted at its own step (chain.c:304)
+			// is the predecessor emitted at its own step?  in-tile predecessors: ask their lane
+			const int srcp = ((pi >= c.tile0 ? pi - c.tile0 : hl) + (h << 5)) << 2;
+			const int pself_in = __builtin_amdgcn_ds_bpermute(srcp, self ? 1 : 0);
+			const bool pred_self = ext ? ext_self : pself_in != 0;
+			wave_mem_fence();
+			if (have) tw_st32((((uint32_t)i_lane & 63u) << 3 | (uint32_t)h << 2) + TW_V, val | (self ? INT_MIN : 0));
+			wave_mem_fence();
+			if (have && !self) g.first_child[gi] = NO_CHILD;             // before any child (this tile or later, always this half) lowers it
+			if (__builtin_amdgcn_ballot_w64(have && !self)) wave_global_fence();
+			if (have) {
+				g.f[gi] = fi;
+				g.p[gi] = pi < 0 ? -1 : pi + c.rel0;
+				g.v[gi] = val;
+				int maybe_first = 0;
+				if (pi >= 0 && !pred_self) { atomicMin(&g.first_child[c.base + pi], c.rel0 + i_lane); maybe_first = 4; }
+				g.flags[gi] = (uint8_t)((self ? 2 : 0) | maybe_first | (val >= g.par.min_sc ? 8 : 0) | (fi < val ? 16 : 0));
+			}
+		}
+		// ---- (b), (c): next tile of the unit, or the half's next unit; loops while units end exactly on a tile boundary or are handed over
+		bool need = mine;
+		bool fresh_unit = false;
+		if (mine) {
+			c.tile0 += 32;
+			// a unit that keeps needing second chunks (more than one anchor in eight) is cheaper in k_chain_units: hand the rest of it
+			// -- that is, all of it, from scratch -- over
+			if (cnt_prev == 32 && c.tile0 < c.room && c.tile0 >= 64 && u.slow * 8 > c.tile0) {
+				if (hl == 0) { Unit un; un.start = c.base; un.read = c.read; un.len = c.room; g.left[atomicAdd(g.left_cnt, 1u)] = un; }
+				cnt_prev = 0;                                                // "the unit is finished"
+			}
+		}
+		while (__builtin_amdgcn_ballot_w64(need)) {
+			if (need) {
+				const bool unit_done = cnt_prev < 32 || c.tile0 >= c.room;   // the finished tile was the unit's last (or there is no unit yet)
+				if (unit_done) {
+					for (;;) {                                            // pick units until one is taken by this kernel
+						if (c.next >= n_units) { live = false; break; }
+						const Unit un = g.units[c.next];
+						c.next += 2 * (int64_t)gridDim.x;
+						const int64_t rs = g.off[un.read];
+						const unsigned long long sq = g.sumq[un.read];
+						const bool general = !params_ok || (sq & (SUMQ_SEG_FLAG | SUMQ_LUT16_FLAG)) || g.par.n_segs > 1;
+						if (general) {                                    // not for this kernel: hand the unit over
+							if (hl == 0) g.left[atomicAdd(g.left_cnt, 1u)] = un;
+							continue;
+						}
+						c.base = un.start; c.rel0 = (int)(un.start - rs); c.room = un.len; c.read = un.read; c.tile0 = 0;
+						fresh_unit = true;
+						break;
+					}
+					if (!live) { need = false; u.pc = curbase; u.pend = curbase; }
+				}
+			}
+			if (need) {
+				if (fresh_unit) {
+					// LDS of the half for a new unit: marks never match, every XY slot fails the window test, the read's table (as bytes)
+					const uint2 *src = (const uint2*)(g.lut + (int64_t)c.read * g.lut_stride);
+					wave_mem_fence();
+					for (int k = hl; k * 4 <= g.par.bw; k += 32) {                 // lut_stride is a multiple of 8 entries: whole uint2 loads
+						const uint2 t = src[k];
+						const uint32_t w = (t.x & 0xffu) | (t.x >> 8 & 0xff00u) | (t.y << 16 & 0xff0000u) | (t.y << 8 & 0xff000000u);
+						tw_st32(c_lut + ((uint32_t)k << 2), (int)w);
+					}
+					const uint32_t x_none = (uint32_t)g.a[c.base].x - (uint32_t)maxx - 1u;    // "no anchor here" in the x+1 encoding
+					for (int k = hl; k < 128; k += 32) tw_st64(((uint32_t)k << 4 | c_8h) + TW_XY, x_none, 0u);
+					for (int k = hl; k < 65; k += 32) tw_st32(mkbase + ((uint32_t)k << 2), -1);
+					wave_mem_fence();
+					c.x_carry = 0;
+					u.slow = 0;
+				}
+				// the tile: 32 anchors, one 16-byte load per lane
+				const int i_lane = c.tile0 + hl;
+				const bool have = i_lane < c.room;
+				ulonglong2 an = make_ulonglong2(0, 0);
+				if (have) an = g.a[c.base + i_lane];
+				uint64_t xp;
+				{
+					uint32_t lo = (uint32_t)wave_shift_up1((int)(uint32_t)an.x, 0), hi = (uint32_t)wave_shift_up1((int)(uint32_t)(an.x >> 32), 0);
+					if (hl == 0) { lo = (uint32_t)c.x_carry; hi = (uint32_t)(c.x_carry >> 32); }
+					xp = (uint64_t)hi << 32 | lo;
+				}
+				const bool stop = !have || (i_lane > 0 && an.x - xp > maxx);   // the unit ends at the first gap > max_dist_x (chain.c:252)
+				const uint64_t stop_m = __builtin_amdgcn_ballot_w64(stop) & my_half;
+				const uint32_t stop_h = hi_half ? (uint32_t)(stop_m >> 32) : (uint32_t)stop_m;
+				const int cnt = stop_h ? __builtin_ctz(stop_h) : 32;
+				{
+					const int last = (h << 5) + 31;
+					const uint32_t clo = (uint32_t)__builtin_amdgcn_ds_bpermute(last << 2, (int)(uint32_t)an.x);
+					const uint32_t chi = (uint32_t)__builtin_amdgcn_ds_bpermute(last << 2, (int)(uint32_t)(an.x >> 32));
+					c.x_carry = (uint64_t)chi << 32 | clo;
+				}
+				fresh_unit = false;
+				cnt_prev = cnt;
+				u.pc = curbase; u.pend = curbase + ((uint32_t)cnt << 4);
+				if (cnt == 0) continue;                                      // the unit ended exactly on the boundary: unit_done next round
+				// publish the tile: XY ring (for its anchors as predecessors) and CUR (for them as the current anchor)
+				wave_mem_fence();
+				if (hl < cnt) {
+					const int sp = span_of_hi((uint32_t)(an.y >> 32));
+					tw_st64((((uint32_t)i_lane & 127u) << 4 | c_8h) + TW_XY, (uint32_t)an.x + 1u, (uint32_t)an.y + 1u);
+					tw_st128(curbase + ((uint32_t)hl << 4), (uint32_t)an.x, (uint32_t)an.y, (uint32_t)(sp - 1), (uint32_t)sp);
+				}
+				wave_mem_fence();
+				need = false;
+			}
+		}
+		// ---- (d) the tile's first anchor becomes current
+		if (mine && live) {
+			const uint32_t i = (uint32_t)c.tile0;
+			u.maxj4 = -4; u.nskip = 0; u.kb4 = 0;
+			u.j4 = (i - 1u) << 2; u.S = (i - 1u) << 4 | c_8h; u.m4 = ((i - 1u) << 2) + mkbase;
+		}
+		if (mine && hl == 0) TW_COLD = c;
+		wave_mem_fence();
+		live_m &= ~__builtin_amdgcn_ballot_w64(mine && !live);
+		contm &= ~svc;
+	};
+
+	// The tail of a pass in which not both halves finish their scan in their first chunk (or a half is idle): per half either
+	// the next anchor becomes current, or the second chunk follows, or -- still undecided after the second chunk -- the unit is
+	// handed over.  Returns the halves to service.
+	auto slow_tail = [&](uint64_t D, uint32_t a_cur, int nskip_after) -> uint64_t {
+		// There are two chunks.  Lane 31 of the second (j = i - 64) is not evaluated (its PF slot is anchor i's own), so a half
+		// that is still undecided after it is handed over to k_chain_units.
+		const uint64_t giveup = ~D & contm;
+		const int vlast = __builtin_amdgcn_ds_bpermute(((h << 5) + 31) << 2, nskip_after);
+		wave_mem_fence();
+		const tw_u32x2 cur = tw_ld64(a_cur);                                 // the running max just written
+		if (__builtin_amdgcn_inverse_ballot_w64(D)) {
+			u.maxj4 = -4; u.nskip = 0;
+			u.m4 += 4u;
+			u.j4 = u.m4 - c_mkbase; u.S = (u.j4 << 2) | c_8h; u.kb4 = 0;
+			u.pc += 16u;
+		} else {
+			u.nskip = vlast; u.maxj4 = (int)cur.x; u.maxf = (int)cur.y;
+			u.j4 -= 128u; u.S -= 512u; u.kb4 = 128u;
+			++u.slow;
+		}
+		contm = ~D & ~giveup & live_m;
+		if (__builtin_expect(giveup != 0, 0)) {
+			if (__builtin_amdgcn_inverse_ballot_w64(giveup)) {
+				wave_mem_fence();
+				if (hl == 0) {
+					TwinCold c = TW_COLD;
+					Unit un; un.start = c.base; un.read = c.read; un.len = c.room;
+					g.left[atomicAdd(g.left_cnt, 1u)] = un;
+					c.room = 0; TW_COLD = c;                                 // the unit is over for this kernel
+				}
+				u.pc = curbase; u.pend = curbase; u.kb4 = 0;                 // nothing to flush; service() picks the half's next unit
+			}
+			return giveup;
+		}
+		return 0;
+	};
+
+	service(~0ull);
+	bool force_general = false;
+	// ======================================================================================== main loop: one chunk pass per trip
+	while (live_m != 0) {
+		wave_mem_fence();                                                    // PF[i-1] of the previous pass, rings written by service()
+		uint64_t svc = 0;
+		if (__builtin_expect(contm == 0 && live_m == ~0ull && !force_general, 1)) {
+			// ------------------------------------------------------------ both halves in their first chunk (n_skip = 0, max_j = none).
+			// A loop of its own: while both halves finish every scan in the first chunk nothing but the pass below runs, and its
+			// state is updated in place.
+			uint64_t B, X, tile;
+			int cB;
+			uint32_t a_cur;
+			for (;;) {
+				const uint32_t t0 = u.S - L16;                               // lane k <-> predecessor j = jtop - k of its half's anchor
+				const tw_u32x2 xy = tw_ld64((t0 & 0x7f8u) + TW_XY);
+				const tw_u32x2 pf = tw_ld64((t0 & 0x3f8u) + TW_PF);
+				const tw_u32x4 cur = tw_ld128(u.pc);                         // the anchor itself: x, q, q_span - 1, q_span
+				const uint32_t drm1 = cur.x - xy.x, dqm1 = cur.y - xy.y;     // the ring holds x + 1, q + 1: differences minus one
+				const uint32_t ddl = tw_sad(drm1, dqm1, c_lut);              // |dr - dq| + the half's table base
+				const uint32_t dqs = SAMEGAP ? dqm1 : __builtin_elementwise_add_sat(dqm1, c_dqoff);
+				const uint32_t m3 = max(max(drm1, dqs), ddl + c_cbwl);
+				const uint64_t okm = TW_ULT(m3, c_M);                        // chain.c:252-260 as one compare
+				const int sc0 = min(min((int)dqm1, (int)drm1), (int)cur.z);  // chain.c:262-263, minus one
+				const int lutv = tw_ld_i8(min(ddl, c_bwl));
+				const uint32_t dst = TW_SEL(okm, min(u.m4 - pf.x, c_far), c_far);   // marks (chain.c:281) by distance; the others go to the sink
+				tw_st32(dst, (int)u.m4);
+				wave_mem_fence();
+				const int tj = tw_ld32(c_own);
+				const int sc = TW_SEL(okm, sc0 + (int)pf.y + lutv, c_min);   // chain.c:272-273 via the table
+				const int excl = max(tw_excl_max32(sc), (int)cur.w);
+				const uint64_t A = TW_SGT(sc, excl);                         // new running max (chain.c:274); masked lanes hold INT_MIN
+				B = TW_EQ(tj, u.m4) & okm & ~A;                              // marked and not better (chain.c:277)
+				const uint64_t OUT = TW_SGE(drm1, c_Mout);                   // the half's last lane is outside the window (or no anchor there yet)
+				cB = tw_below_in_half(B, hi_half);
+				// n_skip walk (chain.c:276,278) from n_skip = 0.  When every A lane of a half precedes every B lane of it, n_skip at a
+				// B lane is the number of B lanes up to it: the break is the (max_skip + 1)-th of them.  An A lane above a B lane
+				// (interleaved, rare) leaves this loop for the general pass, which redoes the anchor.
+				tile = 0; X = 0; a_cur = 0;
+				if (__builtin_expect((TW_SGT(cB, 0) & A) != 0, 0)) { force_general = true; break; }
+				// the running max goes to PF[i]: the half's last A lane writes its own score and predecessor, or (none) the half's
+				// lane 0 writes "no predecessor, q_span"
+				const uint32_t S1 = u.S + 16u;
+				a_cur = S1 & 0x3f8u;                                         // PF slot of anchor i (S = 16 (i - 1) + 8h in the first chunk)
+				{
+					const uint32_t wp = TW_SEL(A, u.j4 - L4, 0xfffffffcu);
+					const int wf = TW_SEL(A, sc, (int)cur.w);
+					if (__builtin_amdgcn_inverse_ballot_w64(tw_last_or_lane0(A))) tw_st64(a_cur + TW_PF, wp, (uint32_t)wf);
+				}
+				// scan complete: break taken, or the half's last lane is outside the window (x is sorted: nothing older can matter)
+				X = (TW_SGE(cB, c_ms) & B) | OUT;
+				if (__builtin_expect(tw_both_halves(X) == 0, 0)) break;
+				u.m4 += 4u; u.j4 += 4u; u.S = S1;
+				u.pc += 16u;
+				tile = TW_SGE(u.pc, u.pend);
+				if (__builtin_expect(tile != 0, 0)) break;
+				wave_mem_fence();
+			}
+			if (!force_general && tile == 0) {
+				// a half wants its second chunk.  n_skip after the first: #B, as no A lane follows a B lane
+				svc = slow_tail(tw_smear_halves(X), a_cur + TW_PF, cB + (int)__builtin_amdgcn_inverse_ballot_w64(B));
+			}
+		} else {
+			// ------------------------------------------------------------ general pass: second chunks, idle halves, interleaved walks
+			force_general = false;
+			const uint32_t t0 = u.S - L16;
+			const tw_u32x2 xy = tw_ld64((t0 & 0x7f8u) + TW_XY);
+			const tw_u32x2 pf = tw_ld64((t0 & 0x3f8u) + TW_PF);
+			const tw_u32x4 cur = tw_ld128(u.pc);
+			const uint64_t first = ~contm;                                       // halves in their first chunk: running max = q_span, nothing carried
+			const int maxf = TW_SEL(first, (int)cur.w, u.maxf);
+			const uint32_t maxj4 = TW_SEL(first, 0xfffffffcu, (uint32_t)u.maxj4);
+			const int nskip0 = TW_SEL(first, 0, u.nskip);
+			const uint32_t drm1 = cur.x - xy.x, dqm1 = cur.y - xy.y;
+			const uint32_t dd = absdiff_u32(drm1, dqm1);
+			const uint32_t dqs = SAMEGAP ? dqm1 : __builtin_elementwise_add_sat(dqm1, c_dqoff);
+			const uint32_t m3 = max(max(drm1, dqs), dd + c_cbw);
+			// not evaluated: lane 31 of a second chunk (j = i - 64 shares its PF slot with anchor i itself) and idle halves
+			const uint64_t okm = TW_ULT(m3, c_M) & ~(contm & TW_HI31) & live_m;
+			const int sc0 = min(min((int)dqm1, (int)drm1), (int)cur.z);
+			const int lutv = tw_ld_i8(min(dd, c_bw) + c_lut);
+			const uint32_t dst = TW_SEL(okm, min(u.m4 - pf.x, c_far), c_far);
+			tw_st32(dst, (int)u.m4);
+			wave_mem_fence();
+			const int tj = tw_ld32(c_own + u.kb4);
+			const int sc = TW_SEL(okm, sc0 + (int)pf.y + lutv, c_min);
+			const int excl = max(tw_excl_max32(sc), maxf);
+			const uint64_t A = TW_SGT(sc, excl);
+			const uint64_t B = TW_EQ(tj, u.m4) & okm & ~A;
+			const uint64_t OUT = TW_SGE(drm1, c_M);
+			const int cB = tw_below_in_half(B, hi_half), cA = tw_below_in_half(A, hi_half);
+			const int isA = (int)__builtin_amdgcn_inverse_ballot_w64(A), isB = (int)__builtin_amdgcn_inverse_ballot_w64(B);
+			const uint64_t inter = TW_SGT(cB, 0) & A;
+			uint64_t brk, Ap;
+			int nskip_after;
+			if (inter == 0) {
+				// at a B lane all A lanes of the half are below it: n_skip = max(n0 - #A, 0) + #B up to and including it
+				nskip_after = max(nskip0 - cA - isA, 0) + cB + isB;
+				brk = TW_SGT(nskip_after, c_ms) & B;
+				Ap = A;
+			} else {
+				const int Sk = nskip0 + cB + isB - cA - isA;
+				nskip_after = Sk - min(tw_incl_min32(Sk), 0);
+				brk = TW_SGT(nskip_after, c_ms) & B;
+				Ap = tw_below_first(A, brk);
+			}
+			const uint32_t a_cur = (((((u.m4 - c_mkbase) + 4u) << 2) & 0x3f8u) | c_8h) + TW_PF;   // PF slot of anchor i (m4 = 4 (i - 1) + mark base)
+			{
+				const uint32_t wp = TW_SEL(Ap, u.j4 - L4, maxj4);
+				const int wf = TW_SEL(Ap, sc, maxf);
+				if (__builtin_amdgcn_inverse_ballot_w64(tw_last_or_lane0(Ap))) tw_st64(a_cur, wp, (uint32_t)wf);
+			}
+			const uint64_t D = tw_smear_halves(brk | (OUT & TW_HI31) | ~live_m);   // idle halves count as done
+			svc = slow_tail(D, a_cur, nskip_after);
+		}
+		// ---------------------------------------------------------------- tile exhausted (or unit handed over): flush, next tile / unit
+		svc |= tw_smear_halves(TW_SGE(u.pc, u.pend) & live_m & ~contm);
+		if (__builtin_expect(svc != 0, 0)) service(svc & live_m);
+	}
+#undef TW_COLD
+}
+
+size_t twin_lds_bytes() { return TW_LDS_BYTES; }
+
+hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
+                             const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride, const Unit *d_units,
+                             const unsigned long long *d_counters, int32_t *d_f, int32_t *d_p, int32_t *d_v,
+                             int32_t *d_first_child, uint8_t *d_flags, Unit *d_left, unsigned int *d_left_cnt, int force_left, int64_t total)
+{
+	if (max_units <= 0) return hipSuccess;
+	int64_t blocks = (max_units + 1) / 2;
+	const int64_t cap = 256LL * 24 * 16;
+	if (blocks > cap) blocks = cap;
+	TwinArgs g;
+	g.par = par; g.off = d_off; g.a = (const ulonglong2*)d_a; g.sumq = d_sumq; g.lut = d_lut; g.lut_stride = lut_stride;
+	g.units = d_units; g.counters = d_counters; g.f = d_f; g.p = d_p; g.v = d_v; g.first_child = d_first_child; g.flags = d_flags;
+	g.left = d_left; g.left_cnt = d_left_cnt; g.force_left = force_left; g.total = total;
+	{
+		hipFuncAttributes fa;                                        // LDS is addressed by raw byte offsets from 0: no static LDS may sit in front
+		const void *fn = par.max_dist_y >= par.max_dist_x ? (const void*)k_chain_twin<true> : (const void*)k_chain_twin<false>;
+		const hipError_t e = hipFuncGetAttributes(&fa, fn);
+		if (e != hipSuccess) return e;
+		if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
+	}
+	if (par.max_dist_y >= par.max_dist_x) hipLaunchKernelGGL(k_chain_twin<true>, dim3((unsigned)blocks), dim3(64), TW_LDS_BYTES, st, g);
+	else hipLaunchKernelGGL(k_chain_twin<false>, dim3((unsigned)blocks), dim3(64), TW_LDS_BYTES, st, g);
+	return hipGetLastError();
+}
+
+} // namespace chaindp

@@ -95,6 +95,7 @@ __device__ __forceinline__ void wave_global_fence()
 // sumq[r] holds the read's q_span sum (< 2^40); its top bit records "some anchor of the read carries a
 // non-zero segment id", which sends the read's units to the general variant of the DP kernel.
 #define SUMQ_SEG_FLAG (1ull << 63)
+#define SUMQ_LUT16_FLAG (1ull << 62)   // the read's table of 1 - cost does not fit int8 (set by k_build_lut; k_chain_twin hands such reads over)
 
 __device__ __forceinline__ int span_of_hi(uint32_t yhi) { return (int)(yhi & 0xffu); }        // (y>>32)&0xff
 __device__ __forceinline__ int seg_of_hi(uint32_t yhi) { return (int)((yhi >> 16) & 0xffu); } // (y>>48)&0xff

@@ -36,23 +36,23 @@ for k, cs in agg.items():
     print(f"{k}:")
     for c, v in sorted(cs.items()):
         print(f"    {c:26s} {sum(v)/len(v):18.1f}")
-ck = next((k for k in agg if k.startswith("k_chain_units")), None)
-if ck and anchors:
-    c = {k: sum(v) / len(v) for k, v in agg[ck].items()}
-    print(f"\n## {ck}: derived (anchors per launch = {anchors})")
-    for name in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM"):
-        if name in c:
-            print(f"    {name}/anchor = {c[name]/anchors:.2f}")
-    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        rd, wr = 2 * c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
-        print(f"    HBM traffic per launch: read {rd/1e6:.1f} MB (FETCH_SIZE x2 gfx950 correction), write {wr/1e6:.1f} MB,"
-              f" total {(rd+wr)/anchors:.1f} B/anchor (algorithmic 24 B/anchor)")
-        with open(os.path.join(d, "traffic.json"), "w") as fh:
-            json.dump({"kernel": ck, "anchors_per_launch": anchors, "hbm_read_bytes": rd, "hbm_write_bytes": wr,
-                       "hbm_bytes_per_launch": rd + wr,
-                       "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
-                       "lds_insts_per_launch": c.get("SQ_INSTS_LDS"),
-                       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KiB -> bytes, "
-                                 "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B), average over launches"}, fh)
-    if "GRBM_GUI_ACTIVE" in c:
-        print(f"    GRBM_GUI_ACTIVE/8 = {c['GRBM_GUI_ACTIVE']/8/1e6:.2f} M cycles")
+for ck in [k for k in agg if k.startswith("k_chain_twin") or k.startswith("k_chain_units")]:
+  if anchors:
+      c = {k: sum(v) / len(v) for k, v in agg[ck].items()}
+      print(f"\n## {ck}: derived (anchors per launch = {anchors})")
+      for name in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM"):
+          if name in c:
+              print(f"    {name}/anchor = {c[name]/anchors:.2f}")
+      if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+          rd, wr = 2 * c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
+          print(f"    HBM traffic per launch: read {rd/1e6:.1f} MB (FETCH_SIZE x2 gfx950 correction), write {wr/1e6:.1f} MB,"
+                f" total {(rd+wr)/anchors:.1f} B/anchor (algorithmic 24 B/anchor)")
+          with open(os.path.join(d, "traffic.json"), "w") as fh:
+              json.dump({"kernel": ck, "anchors_per_launch": anchors, "hbm_read_bytes": rd, "hbm_write_bytes": wr,
+                         "hbm_bytes_per_launch": rd + wr,
+                         "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
+                         "lds_insts_per_launch": c.get("SQ_INSTS_LDS"),
+                         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KiB -> bytes, "
+                                   "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B), average over launches"}, fh)
+      if "GRBM_GUI_ACTIVE" in c:
+          print(f"    GRBM_GUI_ACTIVE/8 = {c['GRBM_GUI_ACTIVE']/8/1e6:.2f} M cycles")
