@@ -200,7 +200,6 @@ struct TwinCold {
 struct TwinHot {
 	uint32_t S;                       // 16 * jtop + 8h, jtop = i - 1 - 32c: ring offset of lane 0's predecessor
 	uint32_t m4;                      // 4 * (i - 1) + mark base: mark distance base and the scan's tag
-	uint32_t j4;                      // 4 * jtop
 	uint32_t pc, pend;                // CUR entry of the current anchor; end of the tile's entries
 	// constant while a half is in its first chunk:
 	int maxf;                         // running max of the scan (chain.c:274) carried into a second chunk
@@ -218,7 +217,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 	const uint64_t my_half = hi_half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
 
 	// ---- per-lane constants (vector registers on purpose, see TW_VREG)
-	uint32_t L16 = (uint32_t)hl << 4, L4 = (uint32_t)hl << 2;
+	uint32_t L16 = (uint32_t)hl << 4;
 	const uint32_t mkbase = TW_MK + TW_MK_HALF * (uint32_t)h;      // this half's mark words
 	const uint32_t curbase = TW_CUR + TW_CUR_HALF * (uint32_t)h;   // this half's CUR entries
 	uint32_t c_mkbase = mkbase;
@@ -236,8 +235,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 	int c_Mout = hl == 31 ? g.par.max_dist_x : INT_MAX;            // window test that only the half's last lane can fail
 	uint32_t c_bwl = c_bw + c_lut;                                 // table address of the last entry
 	uint32_t c_cbwl = c_cbw - c_lut;                               // (dd + c_lut) + this = dd + c_cbw
-	TW_VREG(L16); TW_VREG(L4); TW_VREG(c_mkbase); TW_VREG(c_far); TW_VREG(c_own); TW_VREG(c_lut); TW_VREG(c_8h); TW_VREG(c_M); TW_VREG(c_bw);
-	TW_VREG(c_cbw); TW_VREG(c_dqoff); TW_VREG(c_ms); TW_VREG(c_min); TW_VREG(c_Mout); TW_VREG(c_bwl); TW_VREG(c_cbwl);
+	TW_VREG(L16); TW_VREG(c_far); TW_VREG(c_own); TW_VREG(c_lut); TW_VREG(c_M);
+	if (!SAMEGAP) TW_VREG(c_dqoff);
+	TW_VREG(c_ms); TW_VREG(c_min); TW_VREG(c_Mout); TW_VREG(c_bwl); TW_VREG(c_cbwl);
 
 	const uint64_t maxx = (uint64_t)(int64_t)g.par.max_dist_x;
 	const int64_t n_units = (int64_t)(uint32_t)g.counters[0];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 	                       ((uint64_t)(int64_t)g.par.max_dist_x + 1) * 129ull < (1ull << 31) && g.par.bw + 1 <= (int)TW_LUT_HALF && !g.force_left;
 
 	TwinHot u;
-	u.S = 0; u.m4 = 0; u.j4 = 0; u.pc = curbase; u.pend = curbase; u.maxf = 0; u.kb4 = 0; u.maxj4 = -4; u.nskip = 0; u.slow = 0;
+	u.S = 0; u.m4 = 0; u.pc = curbase; u.pend = curbase; u.maxf = 0; u.kb4 = 0; u.maxj4 = -4; u.nskip = 0; u.slow = 0;
 	uint64_t live_m = ~0ull;                                       // halves that still have (or may get) work
 	uint64_t contm = 0;                                            // halves that are in their second (= last) chunk
 	const uint32_t st_addr = TW_ST + 64u * (uint32_t)h;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 		if (mine && live) {
 			const uint32_t i = (uint32_t)c.tile0;
 			u.maxj4 = -4; u.nskip = 0; u.kb4 = 0;
-			u.j4 = (i - 1u) << 2; u.S = (i - 1u) << 4 | c_8h; u.m4 = ((i - 1u) << 2) + mkbase;
+			u.S = (i - 1u) << 4 | c_8h; u.m4 = ((i - 1u) << 2) + mkbase;
 		}
 		if (mine && hl == 0) TW_COLD = c;
 		wave_mem_fence();
@@ -433,11 +433,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 		if (__builtin_amdgcn_inverse_ballot_w64(D)) {
 			u.maxj4 = -4; u.nskip = 0;
 			u.m4 += 4u;
-			u.j4 = u.m4 - c_mkbase; u.S = (u.j4 << 2) | c_8h; u.kb4 = 0;
+			u.S = ((u.m4 - c_mkbase) << 2) | c_8h; u.kb4 = 0;
 			u.pc += 16u;
 		} else {
 			u.nskip = vlast; u.maxj4 = (int)cur.x; u.maxf = (int)cur.y;
-			u.j4 -= 128u; u.S -= 512u; u.kb4 = 128u;
+			u.S -= 512u; u.kb4 = 128u;
 			++u.slow;
 		}
 		contm = ~D & ~giveup & live_m;
@@ -502,14 +502,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				const uint32_t S1 = u.S + 16u;
 				a_cur = S1 & 0x3f8u;                                         // PF slot of anchor i (S = 16 (i - 1) + 8h in the first chunk)
 				{
-					const uint32_t wp = TW_SEL(A, u.j4 - L4, 0xfffffffcu);
+					const uint32_t wp = TW_SEL(A, u.m4 - c_own, 0xfffffffcu);      // 4 j of the lane's predecessor: 4 (i - 1 - k)
 					const int wf = TW_SEL(A, sc, (int)cur.w);
 					if (__builtin_amdgcn_inverse_ballot_w64(tw_last_or_lane0(A))) tw_st64(a_cur + TW_PF, wp, (uint32_t)wf);
 				}
 				// scan complete: break taken, or the half's last lane is outside the window (x is sorted: nothing older can matter)
 				X = (TW_SGE(cB, c_ms) & B) | OUT;
 				if (__builtin_expect(tw_both_halves(X) == 0, 0)) break;
-				u.m4 += 4u; u.j4 += 4u; u.S = S1;
+				u.m4 += 4u; u.S = S1;
 				u.pc += 16u;
 				tile = TW_SGE(u.pc, u.pend);
 				if (__builtin_expect(tile != 0, 0)) break;
@@ -531,13 +531,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 			const uint32_t maxj4 = TW_SEL(first, 0xfffffffcu, (uint32_t)u.maxj4);
 			const int nskip0 = TW_SEL(first, 0, u.nskip);
 			const uint32_t drm1 = cur.x - xy.x, dqm1 = cur.y - xy.y;
-			const uint32_t dd = absdiff_u32(drm1, dqm1);
+			const uint32_t ddl = tw_sad(drm1, dqm1, c_lut);
 			const uint32_t dqs = SAMEGAP ? dqm1 : __builtin_elementwise_add_sat(dqm1, c_dqoff);
-			const uint32_t m3 = max(max(drm1, dqs), dd + c_cbw);
+			const uint32_t m3 = max(max(drm1, dqs), ddl + c_cbwl);
 			// not evaluated: lane 31 of a second chunk (j = i - 64 shares its PF slot with anchor i itself) and idle halves
 			const uint64_t okm = TW_ULT(m3, c_M) & ~(contm & TW_HI31) & live_m;
 			const int sc0 = min(min((int)dqm1, (int)drm1), (int)cur.z);
-			const int lutv = tw_ld_i8(min(dd, c_bw) + c_lut);
+			const int lutv = tw_ld_i8(min(ddl, c_bwl));
 			const uint32_t dst = TW_SEL(okm, min(u.m4 - pf.x, c_far), c_far);
 			tw_st32(dst, (int)u.m4);
 			wave_mem_fence();
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 			}
 			const uint32_t a_cur = (((((u.m4 - c_mkbase) + 4u) << 2) & 0x3f8u) | c_8h) + TW_PF;   // PF slot of anchor i (m4 = 4 (i - 1) + mark base)
 			{
-				const uint32_t wp = TW_SEL(Ap, u.j4 - L4, maxj4);
+				const uint32_t wp = TW_SEL(Ap, u.m4 - c_own - u.kb4, maxj4);          // 4 j = 4 (i - 1 - 32 c - k)
 				const int wf = TW_SEL(Ap, sc, maxf);
 				if (__builtin_amdgcn_inverse_ballot_w64(tw_last_or_lane0(Ap))) tw_st64(a_cur, wp, (uint32_t)wf);
 			}
