@@ -362,7 +362,7 @@ static int compact_launch(chaindp_ctx *ctx, const chaindp_params_t *par)
 		size_t flags_bytes = 0, blocks_bytes = 0;
 		chaindp::compact_scratch_bytes(ctx->cap_anchors, &flags_bytes, &blocks_bytes);
 		void *nb[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-		const size_t sz[6] = {na * 4, (nr + 1) * 8, ctx->d_seeds ? 0 : na * sizeof(chaindp_seed_t), blocks_bytes, blocks_bytes, 8};
+		const size_t sz[6] = {na * 4, (nr + 1) * 8, ctx->d_seeds ? 0 : na * sizeof(chaindp_seed_t) + 16, blocks_bytes, blocks_bytes, 8};
 		hipError_t e = hipSuccess;
 		for (int k = 0; k < 6 && e == hipSuccess; ++k) if (sz[k]) e = hipMalloc(&nb[k], sz[k]);
 		if (e != hipSuccess) {
@@ -876,7 +876,7 @@ static int collect_seeds_impl(chaindp_ctx *ctx, const chaindp_index_t *ix, int f
 		return CHAINDP_ERR_CAPACITY;
 	}
 	// unsorted anchors go to the new_seed[] buffer (free at this point of a batch), the sort writes d_a
-	if (!ctx->d_seeds) HIP_TRY(ctx, hipMalloc(&ctx->d_seeds, (size_t)ctx->cap_anchors * sizeof(chaindp_seed_t)));
+	if (!ctx->d_seeds) HIP_TRY(ctx, hipMalloc(&ctx->d_seeds, (size_t)ctx->cap_anchors * sizeof(chaindp_seed_t) + 16));
 	if (ctx->seed_max_n < 0) {
 		int lds_limit = 0;
 		HIP_TRY(ctx, hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device));
@@ -955,12 +955,15 @@ struct PipeSlot {
 	chaindp_seed_t *h_seeds = nullptr;       // pinned
 	unsigned long long *h_n_seeds = nullptr; // pinned
 	hipEvent_t done = nullptr;               // kernels + small downloads of the batch
+	hipEvent_t up = nullptr;                 // the batch's upload
 	int64_t tag = 0, n_reads = 0, total = 0;
 	int state = 0;                           // 0 free, 1 in flight, 2 waited (results in use)
 };
 
 struct chaindp_pipe {
 	int device = -1, depth = 0;
+	hipStream_t s_up = nullptr, s_down = nullptr;   // one stream per copy direction, shared by the slots: uploads and downloads of
+	                                         // different batches then run on different DMA engines, at the same time
 	std::vector<PipeSlot> slots;
 	int head = 0, tail = 0, inflight = 0;    // tail: oldest submitted, head: next to submit
 	std::string err;
@@ -978,11 +981,14 @@ extern "C" void chaindp_pipe_destroy(chaindp_pipe_t *pipe)
 	for (auto &sl : pipe->slots) {
 		if (sl.ctx && sl.ctx->stream) (void)hipStreamSynchronize(sl.ctx->stream);
 		if (sl.done) (void)hipEventDestroy(sl.done);
+		if (sl.up) (void)hipEventDestroy(sl.up);
 		if (sl.h_seeds_off) (void)hipHostFree(sl.h_seeds_off);
 		if (sl.h_seeds) (void)hipHostFree(sl.h_seeds);
 		if (sl.h_n_seeds) (void)hipHostFree(sl.h_n_seeds);
 		if (sl.ctx) chaindp_destroy(sl.ctx);
 	}
+	if (pipe->s_up) { (void)hipStreamSynchronize(pipe->s_up); (void)hipStreamDestroy(pipe->s_up); }
+	if (pipe->s_down) { (void)hipStreamSynchronize(pipe->s_down); (void)hipStreamDestroy(pipe->s_down); }
 	delete pipe;
 }
 
@@ -993,14 +999,21 @@ extern "C" chaindp_pipe_t *chaindp_pipe_create(int device, int depth, int64_t ma
 	chaindp_pipe *pipe = new chaindp_pipe();
 	pipe->device = device; pipe->depth = depth;
 	pipe->slots.resize((size_t)depth);
+	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&pipe->s_up, hipStreamNonBlocking) != hipSuccess ||
+	    hipStreamCreateWithFlags(&pipe->s_down, hipStreamNonBlocking) != hipSuccess) {
+		g_create_error = "chaindp_pipe_create: no usable HIP device (there is no CPU fallback)";
+		chaindp_pipe_destroy(pipe);
+		return nullptr;
+	}
 	for (auto &sl : pipe->slots) {
 		sl.ctx = chaindp_create(device, max_anchors, max_reads);
 		if (!sl.ctx) { chaindp_pipe_destroy(pipe); return nullptr; }
 		const size_t na = (size_t)sl.ctx->cap_anchors, nr = (size_t)sl.ctx->cap_reads;
 		hipError_t e = hipHostMalloc((void**)&sl.h_seeds_off, (nr + 1) * 8, hipHostMallocDefault);
-		if (e == hipSuccess) e = hipHostMalloc((void**)&sl.h_seeds, na * sizeof(chaindp_seed_t), hipHostMallocDefault);
+		if (e == hipSuccess) e = hipHostMalloc((void**)&sl.h_seeds, na * sizeof(chaindp_seed_t) + 16, hipHostMallocDefault);
 		if (e == hipSuccess) e = hipHostMalloc((void**)&sl.h_n_seeds, 64, hipHostMallocDefault);
 		if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.up, hipEventDisableTiming);
 		if (e != hipSuccess) {
 			g_create_error = std::string("chaindp_pipe_create: ") + hipGetErrorString(e);
 			chaindp_pipe_destroy(pipe);
@@ -1034,10 +1047,14 @@ extern "C" int chaindp_pipe_submit(chaindp_pipe_t *pipe, const chaindp_params_t 
 	if (n_reads > ctx->cap_reads || total > ctx->cap_anchors) { pipe->err = "batch exceeds the capacity the pipe was created with"; return CHAINDP_ERR_CAPACITY; }
 	PIPE_TRY(pipe, hipSetDevice(pipe->device));
 	hipStream_t st = ctx->stream;
-	PIPE_TRY(pipe, hipMemcpyAsync(ctx->d_off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, st));
-	if (total) PIPE_TRY(pipe, hipMemcpyAsync(ctx->d_a, a, (size_t)total * 16, hipMemcpyHostToDevice, st));
+	// upload on the pipe's upload stream (the slot's previous batch has been waited for, so its buffers are free); the
+	// slot's own stream takes over for the kernels once the upload is in
+	PIPE_TRY(pipe, hipMemcpyAsync(ctx->d_off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, pipe->s_up));
+	if (total) PIPE_TRY(pipe, hipMemcpyAsync(ctx->d_a, a, (size_t)total * 16, hipMemcpyHostToDevice, pipe->s_up));
 	ctx->has_n_segs = n_segs_per_read != nullptr;
-	if (n_segs_per_read && n_reads) PIPE_TRY(pipe, hipMemcpyAsync(ctx->d_n_segs, n_segs_per_read, (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
+	if (n_segs_per_read && n_reads) PIPE_TRY(pipe, hipMemcpyAsync(ctx->d_n_segs, n_segs_per_read, (size_t)n_reads * 4, hipMemcpyHostToDevice, pipe->s_up));
+	PIPE_TRY(pipe, hipEventRecord(sl.up, pipe->s_up));
+	PIPE_TRY(pipe, hipStreamWaitEvent(st, sl.up, 0));
 	ctx->n_reads = n_reads; ctx->total = total; ctx->ran = false; ctx->bot_n_reads = -1; ctx->mp_resident = false;
 	rc = chaindp_run_full(ctx, par);
 	if (rc) { pipe->err = ctx->err; return rc; }
@@ -1061,8 +1078,11 @@ extern "C" int chaindp_pipe_wait(chaindp_pipe_t *pipe, chaindp_pipe_result_t *re
 	const int64_t m = sl.total > 0 && sl.n_reads > 0 ? (int64_t)(uint32_t)*sl.h_n_seeds : 0;
 	sl.ctx->n_seeds = m;
 	if (m > 0) {
-		PIPE_TRY(pipe, hipMemcpyAsync(sl.h_seeds, sl.ctx->d_seeds, (size_t)m * sizeof(chaindp_seed_t), hipMemcpyDeviceToHost, sl.ctx->stream));
-		PIPE_TRY(pipe, hipStreamSynchronize(sl.ctx->stream));
+		// a few workgroups are enough to fill the link and leave the shader array to the other slots' kernels
+		static const int copy_blocks = getenv("CHAINDP_PIPE_COPY_BLOCKS") ? atoi(getenv("CHAINDP_PIPE_COPY_BLOCKS")) : 64;
+		if (copy_blocks > 0) PIPE_TRY(pipe, chaindp::launch_copy_out(pipe->s_down, sl.h_seeds, sl.ctx->d_seeds, (size_t)m * sizeof(chaindp_seed_t), copy_blocks));
+		else PIPE_TRY(pipe, hipMemcpyAsync(sl.h_seeds, sl.ctx->d_seeds, (size_t)m * sizeof(chaindp_seed_t), hipMemcpyDeviceToHost, pipe->s_down));
+		PIPE_TRY(pipe, hipStreamSynchronize(pipe->s_down));
 	}
 	if (sl.n_reads == 0) sl.h_seeds_off[0] = 0;
 	res->tag = sl.tag; res->n_reads = sl.n_reads; res->n_anchors = sl.total; res->n_seeds = m;

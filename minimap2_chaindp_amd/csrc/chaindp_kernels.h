@@ -134,6 +134,8 @@ size_t seed_sort_lds_bytes(int max_n, int workers, int coop);
 // zero-copy movement between device-visible (pinned) host buffers and HBM: chaindp_io.hip
 hipError_t launch_gather_reads(hipStream_t st, int64_t n_reads, const int64_t *d_off, const void *const *d_src, void *d_a);
 hipError_t launch_scatter_seeds(hipStream_t st, int64_t n_reads, const int64_t *d_seeds_off, void *const *d_dst, const void *d_seeds);
+// rounds bytes up to 16: both buffers must have that much room
+hipError_t launch_copy_out(hipStream_t st, void *h_dst, const void *d_src, size_t bytes, int blocks);
 hipError_t launch_scatter_words(hipStream_t st, int64_t n_reads, const int64_t *d_woff, void *const *d_dst, const void *d_words);
 
 } // namespace chaindp
