@@ -87,6 +87,7 @@ def main():
     off, anchors = shard.generate_shard(gen_preset, rank, world, n_reads, SEED, threads=args.host_threads)
     t_gen = time.time() - t_gen
     total = int(off[-1])
+    n_reads = len(off) - 1                                   # (the skewed job is dealt by anchor count: read counts differ per rank)
     dev = chaindp.Device(dev_index, max_anchors=total + 1, max_reads=n_reads + 1, ring=args.ring or None)
     t_up = time.time()
     dev.upload(off, anchors)

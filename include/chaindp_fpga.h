@@ -9,7 +9,9 @@
  *   fpga_init            fpga.h:37   main.c:512      open the device(s), start the service threads
  *   fpga_finalize        fpga.h:39   main.c:614
  *   fpga_set_params      fpga.h:58   main.c:243      global DP parameters (bw, is_cdna, max_skip, min_sc)
- *   fpga_load_index      fpga.h:62   index.c:102-119 accepted and ignored (seed collection stays on the host)
+ *   fpga_load_index      fpga.h:62   index.c:102-119 the B/H/V/P index image, kept and copied to HBM once per GPU: minimizer packets
+ *                                                    are looked up in it on the device (an image is used once the next call that is
+ *                                                    not fpga_load_index -- fpga_set_params, a submit -- has closed it)
  *   fpga_get_writebuf[_thread] fpga.h:44-45 map.c:439,475; fpga_chaindp.c:104   driver-owned (pinned) packet buffer
  *   fpga_writebuf_submit fpga.h:46   map.c:444,480   hand the filled packet to the device
  *   fpga_get_retbuf      fpga.h:41   fpga_chaindp.c:241   blocking receive of one result packet
@@ -100,9 +102,16 @@ void  fpga_load_index(void *addr, int size, int type);
  * merged into one device batch at most, and the in-flight byte budget after which
  * fpga_get_writebuf_thread answers NULL ("busy, retry": map.c:439-441). */
 void chaindp_fpga_configure(int n_gpus, int max_packets_per_batch, unsigned long max_inflight_bytes);
+/* Capacity of one device batch (per service context; defaults 32 Mi anchors, 512 Ki reads), before fpga_init.  A read
+ * with more anchors than that -- or, for minimizer packets, more seeds -- is answered with err_flag = 1 (map.c:933-944); a
+ * batch whose seeds do not fit is split and retried. */
+void chaindp_fpga_configure_capacity(int64_t max_anchors_per_batch, int64_t max_reads_per_batch);
 /* Counters since fpga_init: st[0] packets, st[1] reads, st[2] anchors, st[3] device batches,
  * st[4] reads answered err_flag=1. */
 void chaindp_fpga_stats(int64_t st[5]);
+/* Per GPU: st[0] device batches, st[1] anchors it has chained.  Returns the number of GPUs in use, -1 on a bad index.
+ * Service threads take packets when they are free, so the node's GPUs split the stream by the work they get done. */
+int chaindp_fpga_stats_gpu(int gpu, int64_t st[2]);
 
 
 #ifdef __cplusplus

@@ -72,6 +72,17 @@ def make_config(preset="ava-ont", **overrides):
     return AgConfig(**d)
 
 
+def offsets(preset="ava-ont", n_reads=1000, seed=1, first_read=0, threads=None, **overrides):
+    """CSR offsets (int64[n_reads+1]) of reads first_read .. first_read+n_reads-1 without their anchors: what a dealer needs to
+    split a job by anchor count."""
+    lib = _load()
+    cfg = make_config(preset, **overrides)
+    threads = threads or min(32, os.cpu_count() or 1)
+    off = np.zeros(n_reads + 1, dtype=np.int64)
+    lib.ag_offsets(C.byref(cfg), seed, first_read, n_reads, off.ctypes.data, threads)
+    return off
+
+
 def generate(preset="ava-ont", n_reads=1000, seed=1, first_read=0, threads=None, out=None, **overrides):
     """Returns (off int64[n_reads+1], anchors uint64[total,2]).
 

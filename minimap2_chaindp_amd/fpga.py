@@ -15,6 +15,8 @@ from .chaindp import SEED_DTYPE
 PKT_MINIMIZERS = 3        # the reference's task packets (map.c:302)
 PKT_ANCHORS = 0x41        # this build's: payload = the read's sorted anchors
 
+SHIM_EXTRA_SYMBOLS = ("chaindp_fpga_configure", "chaindp_fpga_configure_capacity", "chaindp_fpga_stats", "chaindp_fpga_stats_gpu")
+
 DRIVER_SYMBOLS = (
     "fpga_init", "fpga_finalize", "fpga_get_retbuf", "fpga_release_retbuf", "fpga_get_writebuf",
     "fpga_get_writebuf_thread", "fpga_writebuf_submit", "fpga_exit_block", "fpga_set_block",
@@ -74,6 +76,10 @@ def lib():
         L.chaindp_fpga_configure.argtypes = [C.c_int, C.c_int, C.c_ulong]
         L.chaindp_fpga_stats.restype = None
         L.chaindp_fpga_stats.argtypes = [vp]
+        L.chaindp_fpga_configure_capacity.restype = None
+        L.chaindp_fpga_configure_capacity.argtypes = [C.c_int64, C.c_int64]
+        L.chaindp_fpga_stats_gpu.restype = C.c_int
+        L.chaindp_fpga_stats_gpu.argtypes = [C.c_int, vp]
         _lib = L
     return _lib
 
@@ -170,9 +176,11 @@ class Driver:
     """fpga_init ... fpga_finalize bracket (main.c:511-519,605-615) with a receiver thread that plays
     recv_task_thread (fpga_chaindp.c:228-270): blocks in fpga_get_retbuf, copies the packet, releases it."""
 
-    def __init__(self, bw=500, is_cdna=0, max_skip=25, min_sc=40, n_gpus=0, max_packets_per_batch=64, flag=0, max_occ=0, index=None):
+    def __init__(self, bw=500, is_cdna=0, max_skip=25, min_sc=40, n_gpus=0, max_packets_per_batch=64, flag=0, max_occ=0, index=None,
+                 max_anchors_per_batch=32 << 20, max_reads_per_batch=1 << 19):
         self.L = lib()
         self.L.chaindp_fpga_configure(n_gpus, max_packets_per_batch, 0)
+        self.L.chaindp_fpga_configure_capacity(max_anchors_per_batch, max_reads_per_batch)
         if self.L.fpga_init(0) != 0:
             raise chaindp.ChainDPError("fpga_init failed: no GPU (there is no CPU fallback)")
         if index is not None:
@@ -220,6 +228,16 @@ class Driver:
         st = (C.c_int64 * 5)()
         self.L.chaindp_fpga_stats(st)
         return dict(packets=st[0], reads=st[1], anchors=st[2], batches=st[3], err_reads=st[4])
+
+    def stats_gpu(self):
+        """Per GPU in use: (device batches, anchors chained)."""
+        st = (C.c_int64 * 2)()
+        n = self.L.chaindp_fpga_stats_gpu(0, st)
+        out = []
+        for d in range(max(n, 0)):
+            self.L.chaindp_fpga_stats_gpu(d, st)
+            out.append((st[0], st[1]))
+        return out
 
     def close(self):
         self.L.fpga_exit_block()                 # main.c:608

@@ -17,8 +17,24 @@ def shard_range(rank, world, reads_per_gpu):
     return rank * reads_per_gpu, reads_per_gpu
 
 
-def generate_shard(preset, rank, world, reads_per_gpu, seed, threads=None, **overrides):
-    first, n = shard_range(rank, world, reads_per_gpu)
+def generate_shard(preset, rank, world, reads_per_gpu, seed, threads=None, balance=None, **overrides):
+    """Rank `rank`'s share of the seeded job of world * reads_per_gpu reads.
+
+    balance = "reads": reads [rank * reads_per_gpu, (rank + 1) * reads_per_gpu) -- right when reads are alike (ava-ont,
+    map-ont).  balance = "anchors" (the default for the skewed preset, BASELINE configs[4]): the job is cut where the
+    cumulative ANCHOR count crosses k/world of the total, so that a rank with a handful of 1e5-anchor reads does
+    not hold up seven ranks of 1e2-anchor ones; every rank derives the same cuts from the job's offsets."""
+    if balance is None:
+        balance = "anchors" if preset == "skew" else "reads"
+    if balance == "reads" or world == 1:
+        first, n = shard_range(rank, world, reads_per_gpu)
+    elif balance == "anchors":
+        if not (0 <= rank < world):
+            raise ValueError("rank outside world")
+        cuts = split_by_anchors(anchorgen.offsets(preset, n_reads=world * reads_per_gpu, seed=seed, threads=threads, **overrides), world)
+        first, n = int(cuts[rank]), int(cuts[rank + 1] - cuts[rank])
+    else:
+        raise ValueError("balance must be 'reads' or 'anchors'")
     return anchorgen.generate(preset, n_reads=n, seed=seed, first_read=first, threads=threads, **overrides)
 
 

@@ -134,3 +134,85 @@ def test_minimizer_and_anchor_packets_in_one_stream():
         assert seen[r][0].tobytes() == exp.tobytes() and seen[1000 + r][0].tobytes() == exp.tobytes(), r
         assert np.array_equal(seen[r][1], g["mini_pos"][g["mp_off"][r]:g["mp_off"][r + 1]]) and seen[r][2] == int(g["rep_len"][r])
         assert len(seen[1000 + r][1]) == 0 and seen[1000 + r][2] == 0
+
+
+def test_read_beyond_batch_capacity_gets_err_flag_not_exit():
+    """An anchor packet whose read is larger than a device batch is answered the reference's way (err_flag = 1, header only,
+    map.c:933-944 recomputes it on the host); the other reads of the same stream come back chained."""
+    par = P.preset("ava-ont")
+    off, a = ag.generate("ava-ont", n_reads=12, seed=77)
+    sizes = np.diff(off)
+    big = int(np.argmax(sizes))
+    cap = int(np.sort(sizes)[-2]) + 1                                   # every read fits but the largest
+    with fpga.Driver(bw=par.bw, is_cdna=par.is_cdna, max_skip=par.max_skip, min_sc=par.min_sc, max_anchors_per_batch=cap) as drv:
+        for r in range(12):
+            drv.submit(fpga.build_task_packet([(r, a[off[r]:off[r + 1]])], par.max_dist_x, par.max_dist_y), tid=r % 3)
+        results = drv.wait_results(12)
+        st = drv.stats()
+    got = {}
+    for raw in results:
+        for read_id, err, seeds in fpga.parse_result_packet(raw):
+            got[read_id] = (err, seeds)
+    assert st["err_reads"] == 1 and got[big][0] == 1 and got[big][1] is None
+    for r in range(12):
+        if r == big:
+            continue
+        ar = np.ascontiguousarray(a[off[r]:off[r + 1]])
+        f, p, v, _ = ol.oracle_fpv(par, ar)
+        assert got[r][0] == 0 and got[r][1].tobytes() == ol.oracle_compact(par, ar, f, p, v).tobytes(), r
+
+
+def test_minimizer_batch_over_capacity_is_split_and_retried():
+    """Far more seeds than the admission guess (four per minimizer) and than one device batch holds: the batch is halved until
+    its parts fit, only reads that do not fit alone come back with err_flag = 1, every other read is chained as usual."""
+    path = [p for p in SEED_FIXTURES if "syn_repeats_mapont" in p][0]
+    g = np.load(path, allow_pickle=False)
+    pv = [int(x) for x in g["params"]]
+    par = P.ChainParams(max_dist_x=pv[0], max_dist_y=pv[1], bw=pv[2], max_skip=pv[3], min_sc=pv[4], is_cdna=pv[5], n_segs=1)
+    n = len(g["bid"])
+    n_anchors = np.diff(g["a_off"])
+    cap = int(np.sort(n_anchors)[-2]) + 1                               # the largest read does not fit on its own; no two large ones together
+    reads = [(r, g["mini"][g["mini_off"][r]:g["mini_off"][r + 1]], int(g["bid"][r]), int(g["qlen"][r])) for r in range(n)]
+    with fpga.Driver(bw=par.bw, is_cdna=par.is_cdna, max_skip=par.max_skip, min_sc=par.min_sc, flag=int(g["flag"]),
+                     max_occ=int(g["mid_occ"]), index=[g["img_B"], g["img_H"], g["img_V"], g["img_P"]], max_anchors_per_batch=cap) as drv:
+        drv.submit(fpga.build_task_packet(reads, par.max_dist_x, par.max_dist_y, pkt_type=fpga.PKT_MINIMIZERS))   # all reads in ONE packet
+        results = drv.wait_results(1)
+        st = drv.stats()
+    big = int(np.argmax(n_anchors))
+    seen = {}
+    for raw in results:
+        for read_id, err, seeds, mini_pos, rep_len in fpga.parse_result_packet_full(raw):
+            seen[read_id] = (err, seeds, mini_pos, rep_len)
+    assert sorted(seen) == list(range(n))
+    assert seen[big][0] == 1 and st["err_reads"] == int(np.sum(n_anchors > cap)) and st["batches"] > 1
+    for r in range(n):
+        if n_anchors[r] > cap:
+            assert seen[r][0] == 1
+            continue
+        a = np.ascontiguousarray(g["anchors"][g["a_off"][r]:g["a_off"][r + 1]])
+        f, p, v, _ = ol.oracle_fpv(par, a)
+        assert seen[r][0] == 0 and seen[r][1].tobytes() == ol.oracle_compact(par, a, f, p, v).tobytes(), r
+        assert np.array_equal(seen[r][2], g["mini_pos"][g["mp_off"][r]:g["mp_off"][r + 1]]) and seen[r][3] == int(g["rep_len"][r])
+
+
+def test_driver_refuses_malformed_submits_and_double_release():
+    import ctypes as C
+    par = P.preset("ava-ont")
+    off, a = ag.generate("ava-ont", n_reads=2, seed=9)
+    with fpga.Driver(bw=par.bw, is_cdna=0, max_skip=par.max_skip, min_sc=par.min_sc) as drv:
+        L = drv.L
+        pkt = fpga.build_task_packet([(0, a[off[0]:off[1]])], par.max_dist_x, par.max_dist_y)
+        buf = L.fpga_get_writebuf_thread(len(pkt), 0, 0)
+        C.memmove(buf, pkt, len(pkt))
+        assert L.fpga_writebuf_submit(buf, len(pkt) + 64, 1) == -1      # more than the buffer was asked for
+        assert L.fpga_writebuf_submit(buf, 64 + 32, 1) == -1            # the task header does not fit in what was filled in
+        assert L.fpga_writebuf_submit(buf + 8, len(pkt), 1) == -1       # not a driver buffer
+        assert L.fpga_writebuf_submit(buf, len(pkt), 1) == 0            # and the packet itself is fine
+        (raw,) = drv.wait_results(1)
+        assert fpga.parse_result_packet(raw)[0][1] == 0
+        # a result buffer can be released once
+        n = C.c_int(0)
+        drv.submit(pkt)
+        res = drv.wait_results(2)
+        assert len(res) == 2
+        assert L.fpga_release_retbuf(buf) == -1                         # the write buffer went back to the pool with its batch

@@ -20,6 +20,39 @@ def _free_port():
     return p
 
 
+def _worker_skew(rank, world, port, q):
+    """The skewed job (BASELINE configs[4]) dealt by anchor count: the code path `bench.py --gpus N --preset skew` takes."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from minimap2_chaindp_amd import shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    off, a = shard.generate_shard("skew", rank, world, 60, SEED, threads=1)
+    dist.barrier()
+    t_max, n_all = shard.reduce_job(0.5 + rank, int(off[-1]), dist)
+    q.put((rank, len(off) - 1, int(off[-1]), int(a[:, 0].astype(np.int64).sum() & 0x7fffffff) if len(a) else 0, t_max, n_all))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_deal_the_skewed_job_by_anchor_count():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_skew, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=180) for _ in procs)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    from minimap2_chaindp_amd import anchorgen
+    off, a = anchorgen.generate("skew", n_reads=120, seed=SEED, threads=2)
+    (r0, n0, a0, c0, t0, s0), (r1, n1, a1, c1, t1, s1) = res
+    assert n0 + n1 == 120 and a0 + a1 == int(off[-1]) == s0 == s1 and t0 == t1 == 1.5      # the shards tile the job
+    cut = n0
+    assert a0 == int(off[cut]) and c0 == int(a[:int(off[cut]), 0].astype(np.int64).sum() & 0x7fffffff)   # same reads, same anchors
+    assert abs(a0 - a1) <= int(np.diff(off).max())                       # within one (largest) read of even, whatever the read counts
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
