@@ -124,6 +124,9 @@ def main():
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:      # side measurements only in the single-GPU run
         extras = measure_extras(torch, chaindp, dev, par, off, anchors, total)
+        if gen_preset == "ava-ont" and n_reads == READS_PER_GPU:
+            extras["other_configs"] = other_configs(chaindp, params, shard, dev_index, args)
+            extras["map_batch"] = measure_map_batch(chaindp, params, dev_index)
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -154,14 +157,13 @@ def main():
                 "step": "prepass + chain DP + compaction (new_seed[]), inputs and outputs resident in HBM",
             },
             "roofline": {
-                "kernel": "k_chain_units", "bound": "hbm",
+                "kernel": "k_chain_twin (+ k_chain_units for the units it hands over)", "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(total),
                 "algorithmic_bytes_per_anchor": ALGO_BYTES_PER_ANCHOR, "anchors_per_launch": total,
                 "avg_launch_ms": dp_ms,
-                # what actually bounds the kernel: vector-instruction issue.  Instruction count
-                # from the committed PMC pass of this batch, duration live; peak = 1024 SIMDs x 2.4 GHz / 4 cycles.
-                "valu_issue": measured_valu_issue(total, dp_ms),
+                # what actually bounds the kernel: instruction issue
+                "issue": measured_issue(total, dp_ms),
             },
             "kernel_ms": {"prepass": pre_ms, "chain_dp": dp_ms, "compact": cmp_ms},
             "host": {"generate_s": t_gen, "upload_s": t_up, "upload_GBps": total * 16 / t_up / 1e9 if t_up > 0 else None},
@@ -183,6 +185,75 @@ def main():
     dev.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def other_configs(chaindp, params, shard, dev_index, args):
+    """The other single-GPU shapes BASELINE.json names, same step (prepass + chain DP + compaction, resident), a few steps each:
+    configs[2] (map-ont vs a human-size reference, ~50 M anchors), configs[4] (skewed 1e2..1e5 anchors per read) and the WHOLE job
+    of configs[3] (100,000 reads, ~0.6 G anchors, ~10 GB of anchors) on one GPU.  Reported beside the headline, never as `value`."""
+    out = {}
+    for name, gen, preset, reads in (("map_ont_50M", "map-ont", "map-ont", 9_400), ("skew_1e2_1e5", "skew", "ava-ont", 3_000),
+                                     ("full_100k_reads_1gpu", "ava-ont", "ava-ont", 100_000)):
+        try:
+            par = params.preset(preset)
+            off, a = shard.generate_shard(gen, 0, 1, reads, SEED, threads=args.host_threads)
+            tot = int(off[-1])
+            with chaindp.Device(dev_index, max_anchors=tot + 1, max_reads=reads + 1) as d:
+                d.upload(off, a)
+                for _ in range(2):
+                    d.run_full(par)
+                d.sync()
+                d.set_profiling(True); d.kernel_ms(reset=True)
+                n = 5
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    d.run_full(par)
+                d.sync()
+                dt = time.perf_counter() - t0
+                k = d.kernel_ms(reset=True)
+                st = d.stats()
+                out[name] = {"generator": gen, "dp_preset": preset, "reads": reads, "anchors": tot, "units": st["units"], "steps": n,
+                             "ms_per_step": dt / n * 1e3, "anchors_per_s": tot * n / dt,
+                             "kernel_ms": {kk: k[kk][0] / max(k[kk][1], 1) for kk in ("prepass", "chain_dp", "compact")},
+                             "handed_to_one_unit_per_wave_kernel": d.leftover_units()}
+            del off, a
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": repr(e)}
+    return out
+
+
+def measure_map_batch(chaindp, params, dev_index, target_anchors=24_000_000):
+    """The resident pipeline as ONE call (chaindp_map_batch): the reference's minimizers in, its hits (mm_reg1_t) out; seed
+    collection over the index image, chain DP, compaction, backtracking and mm_gen_regs never leave HBM.  Input: the reference's
+    own dump of an all-vs-all run (tests/golden/_big, 600 reads x 8 kb, when present on the box) or else the committed
+    synthetic-repeat fixture, repeated to a batch of ~24 M anchors.  PCIe carries ~5 B in and ~1 B out per anchor instead of
+    16 in and 24 out."""
+    big = os.path.join(ROOT, "tests", "golden", "_big", "big_avaont.npz")
+    path = big if os.path.exists(big) else os.path.join(ROOT, "tests", "golden", "seeds", "syn_repeats_avaont.npz")
+    try:
+        g = np.load(path, allow_pickle=False)
+        pv = [int(x) for x in g["params"]]
+        par = params.ChainParams(max_dist_x=pv[0], max_dist_y=pv[1], bw=pv[2], max_skip=pv[3], min_sc=pv[4], is_cdna=pv[5], n_segs=1)
+        mult = max(1, int(target_anchors // max(len(g["anchors"]), 1)))
+        mini_off = np.concatenate([[0], np.cumsum(np.tile(np.diff(g["mini_off"]), mult))]).astype(np.int64)
+        mini, bid, qlen = np.tile(g["mini"], (mult, 1)), np.tile(g["bid"], mult), np.tile(g["qlen"], mult)
+        n_reads = len(bid)
+        hash_ = (np.arange(n_reads, dtype=np.uint64) * np.uint64(2654435761) % np.uint64(1 << 32)).astype(np.uint32)
+        cap_a = len(g["anchors"]) * mult + 1024
+        with chaindp.Device(dev_index, max_anchors=cap_a, max_reads=n_reads + 1) as d:
+            ix = d.load_index([g["img_B"], g["img_H"], g["img_V"], g["img_P"]])
+            roff, regs, rep, na = d.map_batch(ix, int(g["flag"]), int(g["mid_occ"]), par, pv[7], mini_off, mini, bid, qlen, hash_, regs_cap=cap_a // 8)
+            n = 3
+            t0 = time.perf_counter()
+            for _ in range(n):
+                roff, regs, rep, na = d.map_batch(ix, int(g["flag"]), int(g["mid_occ"]), par, pv[7], mini_off, mini, bid, qlen, hash_, regs_cap=cap_a // 8)
+            dt = (time.perf_counter() - t0) / n
+        return {"input": os.path.relpath(path, ROOT), "repeated": mult, "reads": n_reads, "minimizers": int(mini_off[-1]), "anchors": na,
+                "hits": int(roff[-1]), "seconds_per_batch": dt, "anchors_per_s": na / dt, "minimizers_per_s": int(mini_off[-1]) / dt,
+                "bytes_in_per_anchor": (16 * int(mini_off[-1]) + 20 * n_reads) / max(na, 1), "bytes_out_per_anchor": (80 * int(roff[-1]) + 12 * n_reads) / max(na, 1),
+                "includes": "H2D of minimizers (pageable), collect_seed_hits + sort, prepass + chain DP + compaction, backtrack, mm_gen_regs, D2H of hits"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def measure_extras(torch, chaindp, dev, par, off, anchors, total):
@@ -245,8 +316,8 @@ def measure_extras(torch, chaindp, dev, par, off, anchors, total):
         so = np.ascontiguousarray(off[:k + 1])
         _, _, _, evals = ol.oracle_batch(par, so, np.ascontiguousarray(anchors[:int(so[-1])]), threads=8)
         ex["pair_evals_per_anchor"] = evals / max(int(so[-1]), 1)     # inner-loop executions of the scalar algorithm
-    except Exception:  # noqa: BLE001
-        pass
+    except Exception as e:  # noqa: BLE001
+        ex["pair_evals_error"] = repr(e)
     return ex
 
 
@@ -267,7 +338,7 @@ def pinned_copy_bandwidth(torch, nbytes=1 << 30, reps=3):
     return out
 
 
-def measure_pipelined(torch, chaindp, dev_index, par, off, anchors, total, pageable_rate, n_batches=8, depth=3):
+def measure_pipelined(torch, chaindp, dev_index, par, off, anchors, total, pageable_rate, n_batches=12, depth=3):
     """SURVEY 8d's first metric: anchors/s of the device stage INCLUDING transfers, the way a driver would run it
     (reference fpga_chaindp.c:102-159 / 228-266): batches of the bench size stream through chaindp_pipe_t (three
     contexts, three streams), anchors come from pinned host memory, new_seed[] records land in pinned host memory.
@@ -309,33 +380,53 @@ def measure_pipelined(torch, chaindp, dev_index, par, off, anchors, total, pagea
     return res
 
 
+def kernel_source_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("chaindp_twin.hip", "chaindp_kernels.hip", "chaindp_wave.h"):
+        h.update(open(os.path.join(ROOT, "minimap2_chaindp_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def stored_pmc(anchors_per_launch):
+    """PMC figures of the DP kernel from tools/profile.sh on this same workload (profiles/latest_traffic.json).  PMC collection
+    cannot run inside the timed process, so they are quoted only if they were measured on THIS build of the kernels (hash of
+    their sources) and this batch size; otherwise None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
+        if t.get("anchors_per_launch") == anchors_per_launch and t.get("kernel_source_sha16") == kernel_source_sha16():
+            return t
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
 def measured_traffic(anchors_per_launch):
-    """HBM bytes per launch of the DP kernel from the PMC passes of tools/profile.sh on this same workload
-    (profiles/latest_traffic.json; FETCH_SIZE/WRITE_SIZE collected and corrected as MI355X_MICROARCH.md
-    prescribes).  PMC collection cannot run inside the timed process, so this is null unless a profile of the
-    same batch size is committed."""
-    path = os.path.join(ROOT, "profiles", "latest_traffic.json")
-    try:
-        t = json.load(open(path))
-        if t.get("anchors_per_launch") == anchors_per_launch:
-            return t["hbm_bytes_per_launch"]
-    except Exception:  # noqa: BLE001
-        pass
-    return None
+    """HBM bytes per launch of the DP kernel (FETCH_SIZE/WRITE_SIZE collected and corrected as MI355X_MICROARCH.md prescribes)."""
+    t = stored_pmc(anchors_per_launch)
+    return t["hbm_bytes_per_launch"] if t else None
 
 
-def measured_valu_issue(anchors_per_launch, dp_ms):
-    path = os.path.join(ROOT, "profiles", "latest_traffic.json")
-    try:
-        t = json.load(open(path))
-        if t.get("anchors_per_launch") == anchors_per_launch and t.get("valu_insts_per_launch") and dp_ms > 0:
-            peak = 256 * 4 * 2.4e9 / 4 / 1e9                                     # G wave-instructions/s
-            ach = t["valu_insts_per_launch"] / (dp_ms * 1e-3) / 1e9
-            return {"insts_per_anchor": t["valu_insts_per_launch"] / anchors_per_launch, "achieved": ach, "peak": peak,
-                    "unit": "G wave-instructions/s", "frac": ach / peak}
-    except Exception:  # noqa: BLE001
-        pass
-    return None
+# instruction-issue ceilings of the chip, measured by tools/issue_calib.hip (profiles/r02_issue_calib_*.json), G wave-instructions/s
+VALU_FULL_RATE, VALU_HALF_RATE, SALU_RATE = 962.0, 590.0, 574.0
+
+
+def measured_issue(anchors_per_launch, dp_ms):
+    """What actually bounds the DP kernel: instruction issue, not HBM.  Instruction counts from the stored PMC pass (same build,
+    same batch), duration live.  A VALU instruction issues at the full rate only if it is a plain two-source one; SGPR operands,
+    three sources, DPP and compares run at half of it, so the VALU ceiling lies between the two figures; the scalar unit is
+    shared by a CU's four SIMDs."""
+    t = stored_pmc(anchors_per_launch)
+    if not t or dp_ms <= 0 or not t.get("valu_insts_per_launch"):
+        return None
+    sec = dp_ms * 1e-3
+    out = {"valu": {"insts_per_anchor": t["valu_insts_per_launch"] / anchors_per_launch, "achieved": t["valu_insts_per_launch"] / sec / 1e9,
+                    "ceiling_all_full_rate": VALU_FULL_RATE, "ceiling_all_half_rate": VALU_HALF_RATE},
+           "unit": "G wave-instructions/s", "ceilings_from": "tools/issue_calib.hip on MI355X (profiles/r02_issue_calib_*.json)"}
+    if t.get("salu_insts_per_launch"):
+        out["salu"] = {"insts_per_anchor": t["salu_insts_per_launch"] / anchors_per_launch, "achieved": t["salu_insts_per_launch"] / sec / 1e9,
+                       "ceiling": SALU_RATE, "frac": t["salu_insts_per_launch"] / sec / 1e9 / SALU_RATE}
+    return out
 
 
 def cpu_baseline(par, off, anchors, sample_anchors, threads):
@@ -359,7 +450,7 @@ def cpu_baseline(par, off, anchors, sample_anchors, threads):
     except AttributeError:
         usable = os.cpu_count() or 1
     legs = {}
-    for th in sorted({max(1, threads), usable}):
+    for th in sorted({max(1, threads), usable} | {t for t in (32, 64, 128) if t < usable}):
         th = min(th, n)                                         # at least one read per thread
         reps = int(max(1, min(8, round(15.0 * rate1 / int(soff[-1])))))   # ~15 core-seconds per leg
         sec, _ = ol.time_top(par, soff, sa, threads=th, use_ref=use_ref, reps=reps)
@@ -377,6 +468,8 @@ def cpu_baseline(par, off, anchors, sample_anchors, threads):
         "single_core_value": rate1, "by_threads": [legs[t] for t in sorted(legs)],
         "best_threads": best_th, "best_value": legs[best_th]["anchors_per_s"],
         "host_logical_cpus": os.cpu_count(), "usable_cpus": usable,
+        "note": "value is the rate with every logical CPU the process may use; where more threads are SLOWER than fewer (by_threads), the "
+                "box's CPU time is capped for this job (a one-GPU lease gets a share of the host) and best_value is the CPU rate to compare with",
     }
 
 

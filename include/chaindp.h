@@ -177,6 +177,21 @@ int chaindp_collect_seeds_gather(chaindp_ctx_t *ctx, const chaindp_index_t *idx,
 int chaindp_scatter_mini_pos(chaindp_ctx_t *ctx, int64_t n_reads, uint64_t *const *dst);
 int chaindp_download_anchors(chaindp_ctx_t *ctx, chaindp_anchor_t *a);      /* the resident batch's anchors */
 
+/* ---- the whole resident pipeline in one call: minimizers in, hits out (SURVEY 8f N2 -> 8a -> N1 -> N4) -----------
+ * What the reference does per read between collect_minimizers and chain_post (map.c:350-366 on the host, 484-568 on the device,
+ * 862 on the host again): collect_seed_hits over the index image, mm_chain_dp_fpga, mm_chain_dp_bottom, mm_gen_regs -- here
+ * for a whole batch with nothing but the minimizers going in (16 B each, about 0.3 per anchor) and the hits coming out (80 B per
+ * chain instead of 24 B per anchor): the anchors, f/p/v, new_seed[] and the chains never leave HBM.
+ *   mini_off / mini / bid / qlen as in chaindp_collect_seeds; hash[r] as in chaindp_gen_regs;
+ *   regs_off[n_reads + 1] receives the CSR offsets of every read's hits, regs the records (room for regs_cap of them:
+ *   CHAINDP_ERR_CAPACITY, with regs_off filled in, if there are more -- call chaindp_gen_regs with a larger buffer then);
+ *   rep_len (may be NULL) and n_anchors (may be NULL: the batch's seed count) are by-products.
+ * Afterwards the batch is resident exactly as after the separate calls (chaindp_est_err, chaindp_download, ... work).
+ * Bit-identical to the separate calls, hence to the reference (tests/test_gpu_regs.py). */
+int chaindp_map_batch(chaindp_ctx_t *ctx, const chaindp_index_t *idx, int flag, int max_occ, const chaindp_params_t *par, int min_cnt,
+                      int64_t n_reads, const int64_t *mini_off, const chaindp_anchor_t *mini, const uint32_t *bid, const int32_t *qlen,
+                      const uint32_t *hash, int64_t *regs_off, chaindp_reg_t *regs, int64_t regs_cap, int32_t *rep_len, int64_t *n_anchors);
+
 /* Pinned host memory (hipHostMalloc) for callers that want DMA-able staging buffers. */
 void *chaindp_host_alloc(size_t bytes);
 void chaindp_host_free(void *p);

@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "chaindp_index_create", "chaindp_index_destroy", "chaindp_collect_seeds", "chaindp_download_mini_pos", "chaindp_download_anchors", "chaindp_collect_seeds_gather", "chaindp_scatter_mini_pos",
     "chaindp_gen_regs", "chaindp_est_err",
     "chaindp_pipe_create", "chaindp_pipe_destroy", "chaindp_pipe_submit", "chaindp_pipe_wait", "chaindp_pipe_release",
-    "chaindp_pipe_last_error",
+    "chaindp_pipe_last_error", "chaindp_map_batch",
 )
 
 # chaindp_reg_t == mm_reg1_t (minimap.h:100-115), 80 bytes; `bits` is the bit-field word (rev = bit 10)
@@ -91,6 +91,7 @@ def lib():
         L.chaindp_scatter_seeds.argtypes = [vp, i64, vp]
         L.chaindp_device_count.argtypes = []
         L.chaindp_download_anchors.argtypes = [vp, vp]
+        L.chaindp_map_batch.argtypes = [vp, vp, i32, i32, P, i32, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]
         L.chaindp_pipe_create.restype = vp
         L.chaindp_pipe_create.argtypes = [i32, i32, i64, i64]
         L.chaindp_pipe_destroy.restype = None
@@ -266,6 +267,26 @@ class Device:
         mp = np.zeros(max(int(mpo[-1]), 1), np.uint64)
         self._check(self._lib.chaindp_download_mini_pos(self._ctx, _ptr(mp)))
         return off, a[:self._total], rep[:n_reads], mpo, mp[:int(mpo[-1])]
+
+    def map_batch(self, index, flag, max_occ, par, min_cnt, mini_off, mini, bid, qlen, hash_, regs_cap=None):
+        """Minimizers in, hits out, everything in between resident (chaindp_map_batch): (regs_off int64[n_reads+1], regs REG_DTYPE[...],
+        rep_len int32[n_reads], n_anchors)."""
+        mini_off = np.ascontiguousarray(mini_off, np.int64)
+        n_reads = len(mini_off) - 1
+        mini = np.ascontiguousarray(mini, np.uint64).reshape(-1, 2)
+        bid = np.ascontiguousarray(bid, np.uint32); qlen = np.ascontiguousarray(qlen, np.int32); hash_ = np.ascontiguousarray(hash_, np.uint32)
+        cap = int(regs_cap) if regs_cap is not None else max(len(mini) // 4, 1024)
+        roff = np.zeros(n_reads + 1, np.int64); rep = np.zeros(max(n_reads, 1), np.int32)
+        regs = np.zeros(max(cap, 1), REG_DTYPE)
+        na = C.c_int64(0)
+        rc = self._lib.chaindp_map_batch(self._ctx, index, int(flag), int(max_occ), C.byref(par), int(min_cnt), n_reads, _ptr(mini_off), _ptr(mini),
+                                         _ptr(bid), _ptr(qlen), _ptr(hash_), _ptr(roff), _ptr(regs), cap, _ptr(rep), C.byref(na))
+        if rc == -2 and int(roff[-1]) > cap:                                   # more hits than guessed: they are resident, fetch them
+            regs = self.gen_regs(hash_, qlen, int(roff[-1]))
+        else:
+            self._check(rc)
+        self._n_reads, self._total = n_reads, int(na.value)
+        return roff, regs[:int(roff[-1])], rep[:n_reads], int(na.value)
 
     # -- device-pointer path (torch tensors or any other HBM allocation)
     def run_device(self, par, n_reads, total, d_off, d_a, d_n_segs, d_f, d_p, d_v, stream=0):

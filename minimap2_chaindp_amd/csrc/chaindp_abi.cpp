@@ -918,6 +918,25 @@ extern "C" int chaindp_collect_seeds_gather(chaindp_ctx_t *ctx, const chaindp_in
 	return collect_seeds_impl(ctx, ix, flag, max_occ, n_reads, mini_off, nullptr, read_mini, bid, qlen, n_segs_per_read, off, rep_len, mini_pos_off);
 }
 
+extern "C" int chaindp_map_batch(chaindp_ctx_t *ctx, const chaindp_index_t *ix, int flag, int max_occ, const chaindp_params_t *par, int min_cnt,
+                                 int64_t n_reads, const int64_t *mini_off, const chaindp_anchor_t *mini, const uint32_t *bid, const int32_t *qlen,
+                                 const uint32_t *hash, int64_t *regs_off, chaindp_reg_t *regs, int64_t regs_cap, int32_t *rep_len, int64_t *n_anchors)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	int rc = check_params(ctx, par);
+	if (rc) return rc;
+	if (!regs_off || regs_cap < 0 || (regs_cap > 0 && !regs) || (n_reads > 0 && !hash)) { ctx->err = "NULL output or hash"; return CHAINDP_ERR_ARG; }
+	// seeds (resident), DP + compaction, chains, hits: every stage reads what the one before left in HBM
+	if ((rc = collect_seeds_impl(ctx, ix, flag, max_occ, n_reads, mini_off, mini, nullptr, bid, qlen, nullptr, nullptr, rep_len, nullptr)) != CHAINDP_OK) return rc;
+	if (n_anchors) *n_anchors = ctx->total;
+	if ((rc = chaindp_run_full(ctx, par)) != CHAINDP_OK) return rc;
+	std::vector<int64_t> b_off((size_t)(n_reads > 0 ? n_reads + 1 : 1));
+	if ((rc = chaindp_backtrack(ctx, par, min_cnt, regs_off, nullptr, b_off.data(), nullptr)) != CHAINDP_OK) return rc;
+	const int64_t n_c = n_reads > 0 ? regs_off[n_reads] : 0;
+	if (n_c > regs_cap) { ctx->err = "more hits than regs has room for (regs_off is valid; chaindp_gen_regs with a larger buffer returns them)"; return CHAINDP_ERR_CAPACITY; }
+	return chaindp_gen_regs(ctx, hash, qlen, regs);
+}
+
 extern "C" int chaindp_scatter_mini_pos(chaindp_ctx_t *ctx, int64_t n_reads, uint64_t *const *dst)
 {
 	if (!ctx) return CHAINDP_ERR_ARG;

@@ -1,5 +1,7 @@
-"""GPU tier, BASELINE.json's full single-GPU size (the benchmark's own batch: 12,500 ava-ont reads, ~76 M
-anchors), checked through properties that need no full-size oracle run:
+"""GPU tier, BASELINE.json's full single-GPU sizes -- configs[3]'s per-GPU shard (the benchmark's own batch: 12,500 ava-ont
+reads, ~76 M anchors), configs[2] (map-ont against a human-size reference, 24 targets, 32-bit positions, ~50 M anchors) and
+configs[4] (skewed batch, 1e2 .. 1e5 anchors per read, the generator's full default range) -- checked through properties that
+need no full-size oracle run:
   * local consistency: p[i] < i within the window, f[i] = f[p[i]] + pair score(i, p[i]) recomputed exactly
     (including the reference's f64 gap cost), f[i] = q_span where p[i] = -1, v[i] = max(f[i], v[p[i]]);
   * partition invariance: chaining two halves of the batch separately gives the same arrays (reads are
@@ -32,11 +34,22 @@ def _checksum_inner(h, arrs):
     return int(h)
 
 
-def test_full_size_batch_properties():
-    par = P.preset("ava-ont")
-    off, a = shard.generate_shard("ava-ont", 0, 1, READS, SEED, threads=16)
+CONFIGS = [  # generator preset, DP preset, reads, least anchors expected
+    ("ava-ont", "ava-ont", 12_500, 60_000_000),      # configs[3], one GPU's shard
+    ("map-ont", "map-ont", 9_400, 45_000_000),       # configs[2]
+    ("skew", "ava-ont", 3_000, 25_000_000),          # configs[4], skew_min = 100, skew_max = 100000 (the preset's defaults)
+]
+
+
+@pytest.mark.parametrize("gen,preset,READS,least", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_full_size_batch_properties(gen, preset, READS, least):
+    par = P.preset(preset)
+    off, a = shard.generate_shard(gen, 0, 1, READS, SEED, threads=16)
     tot = int(off[-1])
-    assert tot > 60_000_000
+    assert tot > least
+    if gen == "skew":
+        n = np.diff(off)
+        assert n.min() < 400 and n.max() > 50_000                    # the batch really spans the stated range
     with chaindp.Device(0, max_anchors=tot + 1, max_reads=READS + 1) as dev:
         f, p, v = dev.chain_batch(par, off, a)
         soff, seeds = dev.compact(par)

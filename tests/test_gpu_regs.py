@@ -65,6 +65,32 @@ def test_fixture_minimizers_to_hits_without_leaving_the_device(dev, path):
 
 
 @pytest.mark.parametrize("path", REGS, ids=[os.path.basename(p)[:-4] for p in REGS])
+def test_map_batch_minimizers_in_hits_out_equals_the_references_records(dev, path):
+    """chaindp_map_batch: the reference's minimizers and index image in, its own mm_gen_regs records (tests/golden/regs/*.npz,
+    made by the unmodified reference from the same reads) out, in one call with nothing else crossing PCIe -- and equal, byte
+    for byte, to the stage-by-stage calls.  A second call with too little room reports the capacity and leaves the hits
+    resident."""
+    k = np.load(path, allow_pickle=False)
+    g = np.load(os.path.join(os.path.dirname(os.path.dirname(path)), "seeds", os.path.basename(path)), allow_pickle=False)
+    pv = [int(x) for x in g["params"]]
+    par = P.ChainParams(max_dist_x=pv[0], max_dist_y=pv[1], bw=pv[2], max_skip=pv[3], min_sc=pv[4], is_cdna=pv[5], n_segs=1)
+    ix = dev.load_index([g["img_B"], g["img_H"], g["img_V"], g["img_P"]])
+    roff, regs, rep_len, n_anchors = dev.map_batch(ix, int(g["flag"]), int(g["mid_occ"]), par, int(k["min_cnt"]), g["mini_off"], g["mini"],
+                                                  g["bid"], g["qlen"], k["hash"])
+    assert np.array_equal(roff, k["chains_off"]) and n_anchors == len(g["anchors"]) and np.array_equal(rep_len, g["rep_len"])
+    assert regs.tobytes() == k["regs"].view(ol.REG_DTYPE).reshape(-1).tobytes(), "mm_gen_regs records of the reference"
+    if len(regs) > 1:
+        roff2, regs2, _, _ = dev.map_batch(ix, int(g["flag"]), int(g["mid_occ"]), par, int(k["min_cnt"]), g["mini_off"], g["mini"],
+                                           g["bid"], g["qlen"], k["hash"], regs_cap=1)             # too small: fetched afterwards
+        assert np.array_equal(roff2, roff) and regs2.tobytes() == regs.tobytes()
+    # the batch is resident as after the separate calls: the divergence estimate works on it, with the device's mini_pos
+    got, n_match, n_tot = dev.est_err(roff, regs, k["qlen"], k["ref_len"])
+    exp_div = k["regs_div"].view(ol.REG_DTYPE).reshape(-1)
+    unset = exp_div["div"] < 0
+    assert np.array_equal(got["div"] < 0, unset) and np.allclose(got["div"][~unset], exp_div["div"][~unset], rtol=DIV_RTOL, atol=0)
+
+
+@pytest.mark.parametrize("path", REGS, ids=[os.path.basename(p)[:-4] for p in REGS])
 def test_hits_match_the_committed_reference_records(dev, path):
     """From the fixture's anchors to the reference's own mm_gen_regs / mm_est_err records (tests/golden/regs/*.npz, made by
     the unmodified reference): DP, new_seed[], chains and hits on the GPU."""

@@ -5,12 +5,24 @@ DP kernel.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (
 the bytes of wide coalesced reads); FETCH_SIZE/WRITE_SIZE are in KiB."""
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
 from collections import defaultdict
 
 d = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_sha16():
+    """Hash of the chain DP kernels' sources: bench.py only quotes stored PMC figures for the build they were measured on."""
+    h = hashlib.sha256()
+    for f in ("chaindp_twin.hip", "chaindp_kernels.hip", "chaindp_wave.h"):
+        h.update(open(os.path.join(ROOT, "minimap2_chaindp_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 short = lambda n: n.split("(")[0].replace("void ", "").replace("chaindp::", "")
 print(f"# profile summary of {os.path.basename(d)}")
 try:
@@ -47,11 +59,11 @@ for ck in [k for k in agg if k.startswith("k_chain_twin") or k.startswith("k_cha
           rd, wr = 2 * c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
           print(f"    HBM traffic per launch: read {rd/1e6:.1f} MB (FETCH_SIZE x2 gfx950 correction), write {wr/1e6:.1f} MB,"
                 f" total {(rd+wr)/anchors:.1f} B/anchor (algorithmic 24 B/anchor)")
-          with open(os.path.join(d, "traffic.json"), "w") as fh:
+          with open(os.path.join(d, "traffic.json" if ck.startswith("k_chain_twin") or not any(k.startswith("k_chain_twin") for k in agg) else "traffic_units.json"), "w") as fh:
               json.dump({"kernel": ck, "anchors_per_launch": anchors, "hbm_read_bytes": rd, "hbm_write_bytes": wr,
                          "hbm_bytes_per_launch": rd + wr,
                          "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
-                         "lds_insts_per_launch": c.get("SQ_INSTS_LDS"),
+                         "lds_insts_per_launch": c.get("SQ_INSTS_LDS"), "kernel_source_sha16": kernel_source_sha16(),
                          "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, KiB -> bytes, "
                                    "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B), average over launches"}, fh)
       if "GRBM_GUI_ACTIVE" in c:
