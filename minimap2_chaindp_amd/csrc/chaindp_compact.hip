@@ -18,6 +18,7 @@
 // tests compare the bytes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "chaindp_kernels.h"
 
 namespace chaindp {
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t to
                                                      const int64_t *__restrict__ off, const int32_t *__restrict__ p,
                                                      const int32_t *__restrict__ first_child,
                                                      uint8_t *__restrict__ flags, unsigned long long *__restrict__ block_cnt,
-                                                     const int2 *__restrict__ block_reads)
+                                                     const int2 *__restrict__ block_reads, uint16_t *__restrict__ sub)
 {
 	const int lane = threadIdx.x & 63;
 	const int64_t blk = (int64_t)blockIdx.x * (CMP_BLOCK / 64) + (threadIdx.x >> 6);
@@ -155,8 +156,12 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t to
 			mine += (unsigned int)__builtin_popcount(w & 0x03030303u);    // late + self per anchor
 		}
 	}
-	for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d, 64);
-	if (lane == 0) block_cnt[blk] = mine;
+	// records in front of each lane's 16 anchors inside the block: lets k_emit_seeds find the position of any anchor of an earlier
+	// block from block_base[] + this + at most 15 flag bytes
+	unsigned int incl = mine;
+	for (int d = 1; d < 64; d <<= 1) { const unsigned int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+	sub[blk * 64 + lane] = (uint16_t)(incl - mine);
+	if (lane == 63) block_cnt[blk] = incl;
 }
 
 // C3: positions.  block_base = exclusive scan of block_cnt.  Writes batch-global ids and seeds_off[r] at every
@@ -211,6 +216,108 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_positions(int64_t n_reads, int64_
 			if (ge == rs) for (int64_t q = r; q >= 0 && off[q] == rs; --q) seeds_off[q] = (int64_t)pos;
 			pos += (fl & 1) + ((fl >> 1) & 1);
 		}
+	}
+}
+
+// C3 + C4 in one pass (no id[] array in between): positions of a 1024-anchor block's records from the scanned block counts and
+// the block's flag bytes, kept in LDS; records written from there.  What a record needs from OUTSIDE the block -- the position of
+// a predecessor (or of its first child) in an earlier block, the offset of a read that started in an earlier block -- is
+// recomputed from block_base[] and the flag bytes in front of it (a short loop, needed by about one anchor in a hundred).
+__device__ __forceinline__ uint32_t pos_before(const uint8_t *__restrict__ flags, const unsigned long long *__restrict__ block_base,
+                                               const uint16_t *__restrict__ sub, int64_t x)
+{
+	const int64_t bx = x / CMP_PER_BLOCK, b0 = bx * CMP_PER_BLOCK;
+	const int l16 = (int)((x - b0) >> 4);                            // k_count's lane: 16 anchors each
+	uint32_t c = (uint32_t)block_base[bx] + sub[bx * 64 + l16];
+	const int64_t s0 = b0 + 16 * l16;
+	const uint32_t *w = (const uint32_t*)(flags + s0);               // the array is 16-byte aligned and padded
+	const int nfull = (int)((x - s0) >> 2), tail = (int)((x - s0) & 3);
+	for (int k = 0; k < nfull; ++k) c += (uint32_t)__builtin_popcount(w[k] & 0x03030303u);
+	if (tail) c += (uint32_t)__builtin_popcount(w[nfull] & 0x03030303u & ((1u << (8 * tail)) - 1u));
+	return c;
+}
+
+__global__ __launch_bounds__(CMP_BLOCK) void k_emit_seeds(Params par, int64_t n_reads, int64_t total,
+                                                          const int64_t *__restrict__ off, const ulonglong2 *__restrict__ a,
+                                                          const int32_t *__restrict__ f, const int32_t *__restrict__ p,
+                                                          const int32_t *__restrict__ v, const uint8_t *__restrict__ flags,
+                                                          const int32_t *__restrict__ first_child,
+                                                          const unsigned long long *__restrict__ block_base,
+                                                          int64_t *__restrict__ seeds_off, SeedRec *__restrict__ seeds,
+                                                          const int2 *__restrict__ block_reads, const uint16_t *__restrict__ sub)
+{
+	__shared__ uint32_t s_pos[CMP_PER_BLOCK];                        // position of the first record an anchor emits (were it to emit any)
+	__shared__ uint8_t s_fl[CMP_PER_BLOCK];
+	__shared__ uint32_t s_wsum[CMP_BLOCK / 64];
+	__shared__ uint32_t s_so_lo;                                     // seeds_off of the block's first read
+	const int64_t g0 = (int64_t)blockIdx.x * CMP_PER_BLOCK;
+	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
+	int64_t rlo, rhi;
+	block_read_range(block_reads, rlo, rhi);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int min_sc = par.min_sc;
+	const int64_t g = g0 + 4 * (int64_t)threadIdx.x;                 // four consecutive anchors per thread
+	uint32_t w = 0;
+	int n = 0;
+	if (g < g1) {
+		w = *(const uint32_t*)(flags + g);
+		n = g1 - g < 4 ? (int)(g1 - g) : 4;
+		if (n < 4) w &= (1u << (8 * n)) - 1u;
+	}
+	const uint32_t mine = (uint32_t)__builtin_popcount(w & 0x03030303u);
+	uint32_t incl = mine;
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+	if (lane == 63) s_wsum[wave] = incl;
+	if (threadIdx.x == 0) {
+		const int64_t rs = off[rlo];
+		s_so_lo = rs >= g0 ? 0xffffffffu : pos_before(flags, block_base, sub, rs);    // (a read that starts in this block: from s_pos below)
+	}
+	__syncthreads();
+	uint32_t pos = (uint32_t)block_base[blockIdx.x] + incl - mine;
+	for (int k = 0; k < wave; ++k) pos += s_wsum[k];
+	for (int e = 0; e < n; ++e) {
+		const uint32_t fl = (w >> (8 * e)) & 0xffu;
+		s_pos[4 * threadIdx.x + e] = pos; s_fl[4 * threadIdx.x + e] = (uint8_t)fl;
+		pos += (fl & 1) + ((fl >> 1) & 1);
+	}
+	__syncthreads();
+	// position of the first record of anchor x (batch-global index; x <= the block's last anchor)
+	auto pos_of = [&](int64_t x) -> uint32_t { return x >= g0 ? s_pos[x - g0] : pos_before(flags, block_base, sub, x); };
+	auto flag_of = [&](int64_t x) -> uint32_t { return x >= g0 ? (uint32_t)s_fl[x - g0] : (uint32_t)flags[x]; };
+	// records: a thread per anchor, consecutive lanes on consecutive anchors (their records are consecutive too: the stores of a
+	// wave are contiguous)
+	for (int64_t ge = g0 + threadIdx.x; ge < g1; ge += CMP_BLOCK) {
+		const uint32_t fl = s_fl[ge - g0];
+		const uint32_t mypos = s_pos[ge - g0];
+		const int64_t r = rlo == rhi ? rlo : read_of_c(off, rlo, rhi, ge);
+		const int64_t rs = off[r];
+		if (ge == rs) for (int64_t q = r; q >= 0 && off[q] == rs; --q) seeds_off[q] = (int64_t)mypos;   // (empty reads in front share the value)
+		if (!(fl & 2)) continue;                                       // not emitted at its own step
+		const uint32_t so = rs >= g0 ? s_pos[rs - g0] : (r == rlo ? s_so_lo : pos_before(flags, block_base, sub, rs));
+		const int32_t q = p[ge], fk = f[ge];
+		const uint32_t idk = mypos + (fl & 1);
+		int32_t pfield = (int32_t)(0xfffffffcu);                       // (-1)<<2
+		if (q >= 0) {
+			const int64_t qg = rs + q;
+			if (fl & 1) {                                              // late emission of q, chain.c:292-302
+				const int32_t vq = v[qg], fq = f[qg];
+				const ulonglong2 aq = a[qg];
+				SeedRec rec;
+				rec.x = aq.x; rec.y = aq.y; rec.f = fq;
+				rec.p = (int32_t)(0xfffffffcu | (uint32_t)(vq >= min_sc) | ((uint32_t)(fq < vq) << 1));
+				seeds[idk - 1] = rec;
+			}
+			// new index of q: its own record if it is emitted at its own step (behind the late record it may have triggered), else the
+			// slot in front of its first child
+			const uint32_t flq = flag_of(qg);
+			const uint32_t idq = (fl & 1) ? idk - 1 : (flq & 2) ? pos_of(qg) + (flq & 1) : pos_of(rs + first_child[qg]);
+			pfield = (int32_t)((idq - so) << 2);                       // chain.c:310, read-relative index
+		}
+		const ulonglong2 ak = a[ge];
+		SeedRec rec;
+		rec.x = ak.x; rec.y = ak.y; rec.f = fk;
+		rec.p = pfield | ((fl >> 3) & 3);                              // chain.c:313-314: (v >= min_sc) | (f < v) << 1, from the DP kernel
+		seeds[idk] = rec;
 	}
 }
 
@@ -281,12 +388,18 @@ hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, in
 	const int64_t blocks = (total + CMP_PER_BLOCK - 1) / CMP_PER_BLOCK;
 	const dim3 g((unsigned)blocks), b(CMP_BLOCK);
 	const dim3 gw((unsigned)((blocks + CMP_BLOCK / 64 - 1) / (CMP_BLOCK / 64)));    // one wave per 1024-anchor block
-	hipLaunchKernelGGL(k_count, gw, b, 0, st, n_reads, total, d_off, d_p, d_first_child, sc.flags, sc.block_cnt, sc.block_reads);
+	hipLaunchKernelGGL(k_count, gw, b, 0, st, n_reads, total, d_off, d_p, d_first_child, sc.flags, sc.block_cnt, sc.block_reads, sc.sub);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, sc.n_seeds)) != hipSuccess) return e;
-	hipLaunchKernelGGL(k_positions, gw, b, 0, st, n_reads, total, d_off, d_p, sc.flags, sc.block_cnt, d_id, d_seeds_off, sc.block_reads);
+	if (getenv("CHAINDP_COMPACT_TWO_PASS")) {                          // the earlier form (positions to id[], then records), kept for A/B runs
+		hipLaunchKernelGGL(k_positions, gw, b, 0, st, n_reads, total, d_off, d_p, sc.flags, sc.block_cnt, d_id, d_seeds_off, sc.block_reads);
+		hipLaunchKernelGGL(k_finish_offsets, dim3(1), dim3(1), 0, st, n_reads, total, d_off, sc.n_seeds, d_seeds_off);
+		hipLaunchKernelGGL(k_write_seeds, g, b, 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a, d_f, d_p, d_v, sc.flags, d_id,
+		                   d_seeds_off, (SeedRec*)d_seeds, sc.block_reads);
+		return hipGetLastError();
+	}
+	hipLaunchKernelGGL(k_emit_seeds, g, b, 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a, d_f, d_p, d_v, sc.flags, d_first_child,
+	                   sc.block_cnt, d_seeds_off, (SeedRec*)d_seeds, sc.block_reads, sc.sub);
 	hipLaunchKernelGGL(k_finish_offsets, dim3(1), dim3(1), 0, st, n_reads, total, d_off, sc.n_seeds, d_seeds_off);
-	hipLaunchKernelGGL(k_write_seeds, g, b, 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a, d_f, d_p, d_v, sc.flags, d_id,
-	                   d_seeds_off, (SeedRec*)d_seeds, sc.block_reads);
 	return hipGetLastError();
 }
 

@@ -71,6 +71,7 @@ struct CompactScratch {
 	unsigned long long *tile_tmp;
 	unsigned long long *n_seeds;     // total records of the batch
 	const int2 *block_reads;         // PrepassScratch::block_reads of the same batch
+	uint16_t *sub;                   // per 1024-anchor block: records in front of each of its 64 runs of 16 anchors (k_count)
 };
 size_t compact_scratch_bytes(int64_t max_anchors, size_t *flags_bytes, size_t *blocks_bytes);
 hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off,
