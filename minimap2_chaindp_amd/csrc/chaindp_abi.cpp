@@ -257,6 +257,7 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 	if (ctx->variant == 0 && lut && d_n_segs == nullptr) {
 		// ordinary units two per wave; what that kernel hands over (and nothing else) goes through k_chain_units
 		HIP_TRY(ctx, hipMemsetAsync(ctx->d_left_cnt, 0, sizeof(unsigned long long), st));
+		if (total > 0) HIP_TRY(ctx, hipMemsetAsync(ctx->d_first_child, 0x7f, (size_t)total * 4, st));   // NO_CHILD everywhere (chaindp_wave.h)
 		HIP_TRY(ctx, chaindp::launch_chain_twin(st, q, total / 2, d_off, d_a, ctx->d_sumq, lut, lut_stride, ctx->d_units, ctx->d_counters,
 		                                        d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->d_left, (unsigned int*)ctx->d_left_cnt,
 		                                        getenv("CHAINDP_TWIN_FORCE_LEFT") != nullptr, total));

@@ -310,8 +310,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 			wave_mem_fence();
 			if (have) tw_st32((((uint32_t)i_lane & 63u) << 3 | (uint32_t)h << 2) + TW_V, val | (self ? INT_MIN : 0));
 			wave_mem_fence();
-			if (have && !self) g.first_child[gi] = NO_CHILD;             // before any child (this tile or later, always this half) lowers it
-			if (__builtin_amdgcn_ballot_w64(have && !self)) wave_global_fence();
+			// (first_child[] of the whole batch is NO_CHILD when this kernel starts -- one memset by the host -- so that no tile has to
+			// store it and wait for the store before its children's atomics)
 			if (have) {
 				g.f[gi] = fi;
 				g.p[gi] = pi < 0 ? -1 : pi + c.rel0;
@@ -480,12 +480,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				const uint32_t dqs = SAMEGAP ? dqm1 : __builtin_elementwise_add_sat(dqm1, c_dqoff);
 				const uint32_t m3 = max(max(drm1, dqs), ddl + c_cbwl);
 				const uint64_t okm = TW_ULT(m3, c_M);                        // chain.c:252-260 as one compare
-				const int sc0 = min(min((int)dqm1, (int)drm1), (int)cur.z);  // chain.c:262-263, minus one
-				const int lutv = tw_ld_i8(min(ddl, c_bwl));
-				const uint32_t dst = TW_SEL(okm, min(u.m4 - pf.x, c_far), c_far);   // marks (chain.c:281) by distance; the others go to the sink
+				// the mark round trip (chain.c:281: store by distance, the others to the sink; then the lane's own word) and the table
+				// lookup are issued back to back, before anything waits for either
+				const uint32_t dst = TW_SEL(okm, min(u.m4 - pf.x, c_far), c_far);
 				tw_st32(dst, (int)u.m4);
 				wave_mem_fence();
 				const int tj = tw_ld32(c_own);
+				const int lutv = tw_ld_i8(min(ddl, c_bwl));
+#if defined(__HIP_DEVICE_COMPILE__)
+				__builtin_amdgcn_sched_barrier(0);
+#endif
+				const int sc0 = min(min((int)dqm1, (int)drm1), (int)cur.z);  // chain.c:262-263, minus one
 				const int sc = TW_SEL(okm, sc0 + (int)pf.y + lutv, c_min);   // chain.c:272-273 via the table
 				const int excl = max(tw_excl_max32(sc), (int)cur.w);
 				const uint64_t A = TW_SGT(sc, excl);                         // new running max (chain.c:274); masked lanes hold INT_MIN
