@@ -26,6 +26,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
 #include "chaindp_kernels.h"
 #include "chaindp_wave.h"
 
@@ -43,6 +46,7 @@ namespace chaindp {
 #define TW_ST 6176u
 #define TW_LDS_BYTES 6304u
 #define TW_RING 64                      // predecessors a scan can reach in this kernel (two chunks of 32)
+#define TW_QCH 8                        // units a half takes from the queue at a time
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TW_LDS(T, a) ((__attribute__((address_space(3))) T*)(a))
@@ -183,8 +187,10 @@ struct TwinArgs {
 	uint8_t *flags;
 	Unit *left;                       // leftover list for k_chain_units
 	unsigned int *left_cnt;
+	unsigned int *queue;              // next unit nobody has taken yet (the halves' first chunks are dealt statically: it starts behind them)
 	int force_left;                   // test switch: hand every unit over
 	int64_t total;                    // anchors of the batch
+	unsigned long long *stamp;        // diagnostic run (CHAINDP_TWIN_STAMP): per block 8 counters; nullptr otherwise
 };
 
 // the state of a half that only the service path needs lives in LDS (TW_ST + 64 h), so that the pass loop carries
@@ -207,6 +213,15 @@ struct TwinHot {
 	int maxj4, nskip;                 // 4 * max_j (-4: none); n_skip carried into the chunk
 	int slow;                         // second chunks the unit has needed so far
 };
+
+// in-kernel stamps (where a wave's time goes): compiled in only with -DCHAINDP_TWIN_STAMPS, because even switched off they cost
+// registers the kernel does not have to spare (make -C csrc stamps; then run with CHAINDP_TWIN_STAMP=1)
+#ifdef CHAINDP_TWIN_STAMPS
+#define TW_STAMP(...) __VA_ARGS__
+#else
+#define TW_STAMP(...)
+#endif
+#define TW_NOW() __builtin_amdgcn_s_memtime()
 
 template <bool SAMEGAP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_chain_twin(TwinArgs g)
@@ -260,144 +275,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 	const uint32_t st_addr = TW_ST + 64u * (uint32_t)h;
 #define TW_COLD (*TW_LDS(TwinCold, st_addr))
 	if (hl == 0) {
-		TwinCold c0;
-		c0.next = 2 * (int64_t)blockIdx.x + h; c0.base = 0; c0.x_carry = 0; c0.rel0 = 0; c0.room = 0; c0.read = 0; c0.tile0 = -32;
-		TW_COLD = c0;
+		const uint32_t nx = TW_QCH * (2u * blockIdx.x + (uint32_t)h);                   // the half's first chunk of units: dealt statically
+		tw_st128(st_addr, nx, nx + TW_QCH, 0u, 0u);                                     // TwinCold: next (low word: next unit, high word: end of the chunk), base
+		tw_st128(st_addr + 16u, 0u, 0u, 0u, 0u);                                        // x_carry, rel0, room
+		tw_st64(st_addr + 32u, 0u, (uint32_t)-32);                                      // read, tile0
 	}
 	wave_mem_fence();
 
-	// One service round: every lane of the `svc` halves (a) flushes its finished tile, (b) if the unit is finished picks
-	// the half's next unit and prepares its LDS, (c) loads the next tile and publishes it to the rings, (d) makes the
-	// tile's first anchor current.  Divergent (per half) on purpose; executed once per 32 anchors and half.
+	TW_STAMP(unsigned long long st_t0 = 0, st_service = 0, st_slow = 0, st_general = 0, st_n_service = 0, st_n_fast = 0, st_n_general = 0, st_flush = 0, st_unit = 0, st_n_unit = 0;)
+	ulonglong2 an_nx = make_ulonglong2(0, 0);                      // this lane's anchor of its half's NEXT tile, requested a tile ahead
+
+	// One service round for the halves in `svc`, whose tile is exhausted (or which have no unit yet).  One half at a time, with
+	// only its 32 lanes active: everything that is per half (the cold state, the unit being picked, loop conditions) is then
+	// wave-uniform and lives in scalar registers, loads by scalar address go through the scalar cache, and the loops are scalar
+	// branches.  Order: the unit's NEXT tile (requested a tile ago) is taken first -- before the finished tile's f/p/v are stored,
+	// so that nothing waits for those stores --, then the finished tile is flushed; a half whose unit is over picks its next
+	// unit and loads that one's first tile (the one load whose latency is not hidden).  Once per 32 anchors and half.
 	auto service = [&](uint64_t svc) {
-		const bool mine = (svc & my_half) != 0;
 		wave_mem_fence();
-		TwinCold c = TW_COLD;
-		bool live = true;
-		int cnt_prev = (int)(u.pend - curbase) >> 4;                     // anchors of the tile that has just been scored
-		// ---- (a) flush
-		if (mine && cnt_prev > 0) {
-			const int i_lane = c.tile0 + hl;                             // this lane's anchor of the finished tile
-			const bool have = hl < cnt_prev;
-			const int64_t gi = c.base + i_lane;
-			int fi = 0, p4 = -4;
-			if (have) {
-				const tw_u32x2 pf = tw_ld64((((uint32_t)i_lane & 63u) << 4 | c_8h) + TW_PF);
-				p4 = (int)pf.x; fi = (int)pf.y;
-			}
-			const int pi = p4 >> 2;                                      // unit-relative predecessor, -1 = none
-			int val = fi, ptr = have ? pi : -1;
-			const bool ext = ptr >= 0 && ptr < c.tile0;                  // predecessor in an earlier tile: its v is final, in the V ring
-			int vext = 0;
-			if (ext) {
-				vext = tw_ld32((((uint32_t)ptr & 63u) << 3 | (uint32_t)h << 2) + TW_V);
-				val = max(val, vext & 0x7fffffff);
-				ptr = -1;
-			}
-			const bool ext_self = ext && vext < 0;                       // (bit 31 of a V entry: the anchor was emitted at its own step)
-			for (int r = 0; r < 5; ++r) {                                // v[i] = max(f[i], v[p[i]]) (chain.c:284) by pointer doubling over the tile
-				if (__builtin_amdgcn_ballot_w64(ptr >= c.tile0) == 0) break;
-				const int src = ((ptr >= c.tile0 ? ptr - c.tile0 : hl) + (h << 5)) << 2;
-				const int pv = __builtin_amdgcn_ds_bpermute(src, val);
-				const int pp = __builtin_amdgcn_ds_bpermute(src, ptr);
-				if (ptr >= c.tile0) { val = max(val, pv); ptr = pp; }
-			}
-			const bool self = val >= g.par.min_sc || pi >= 0;            // emitted at its own step (chain.c:304)
-			// is the predecessor emitted at its own step?  in-tile predecessors: ask their lane
-			const int srcp = ((pi >= c.tile0 ? pi - c.tile0 : hl) + (h << 5)) << 2;
-			const int pself_in = __builtin_amdgcn_ds_bpermute(srcp, self ? 1 : 0);
-			const bool pred_self = ext ? ext_self : pself_in != 0;
-			wave_mem_fence();
-			if (have) tw_st32((((uint32_t)i_lane & 63u) << 3 | (uint32_t)h << 2) + TW_V, val | (self ? INT_MIN : 0));
-			wave_mem_fence();
-			// (first_child[] of the whole batch is NO_CHILD when this kernel starts -- one memset by the host -- so that no tile has to
-			// store it and wait for the store before its children's atomics)
-			if (have) {
-				g.f[gi] = fi;
-				g.p[gi] = pi < 0 ? -1 : pi + c.rel0;
-				g.v[gi] = val;
-				int maybe_first = 0;
-				if (pi >= 0 && !pred_self) { atomicMin(&g.first_child[c.base + pi], c.rel0 + i_lane); maybe_first = 4; }
-				g.flags[gi] = (uint8_t)((self ? 2 : 0) | maybe_first | (val >= g.par.min_sc ? 8 : 0) | (fi < val ? 16 : 0));
-			}
-		}
-		// ---- (b), (c): next tile of the unit, or the half's next unit; loops while units end exactly on a tile boundary or are handed over
-		bool need = mine;
-		bool fresh_unit = false;
-		if (mine) {
-			c.tile0 += 32;
-			// a unit that keeps needing second chunks (more than one anchor in eight) is cheaper in k_chain_units: hand the rest of it
-			// -- that is, all of it, from scratch -- over
-			if (cnt_prev == 32 && c.tile0 < c.room && c.tile0 >= 64 && u.slow * 8 > c.tile0) {
-				if (hl == 0) { Unit un; un.start = c.base; un.read = c.read; un.len = c.room; g.left[atomicAdd(g.left_cnt, 1u)] = un; }
-				cnt_prev = 0;                                                // "the unit is finished"
-			}
-		}
-		while (__builtin_amdgcn_ballot_w64(need)) {
-			if (need) {
-				const bool unit_done = cnt_prev < 32 || c.tile0 >= c.room;   // the finished tile was the unit's last (or there is no unit yet)
-				if (unit_done) {
-					for (;;) {                                            // pick units until one is taken by this kernel
-						if (c.next >= n_units) { live = false; break; }
-						const Unit un = g.units[c.next];
-						c.next += 2 * (int64_t)gridDim.x;
-						const int64_t rs = g.off[un.read];
-						const unsigned long long sq = g.sumq[un.read];
-						const bool general = !params_ok || (sq & (SUMQ_SEG_FLAG | SUMQ_LUT16_FLAG)) || g.par.n_segs > 1;
-						if (general) {                                    // not for this kernel: hand the unit over
-							if (hl == 0) g.left[atomicAdd(g.left_cnt, 1u)] = un;
-							continue;
-						}
-						c.base = un.start; c.rel0 = (int)(un.start - rs); c.room = un.len; c.read = un.read; c.tile0 = 0;
-						fresh_unit = true;
-						break;
-					}
-					if (!live) { need = false; u.pc = curbase; u.pend = curbase; }
-				}
-			}
-			if (need) {
-				if (fresh_unit) {
-					// LDS of the half for a new unit: marks never match, every XY slot fails the window test, the read's table (as bytes)
-					const uint2 *src = (const uint2*)(g.lut + (int64_t)c.read * g.lut_stride);
-					wave_mem_fence();
-					for (int k = hl; k * 4 <= g.par.bw; k += 32) {                 // lut_stride is a multiple of 8 entries: whole uint2 loads
-						const uint2 t = src[k];
-						const uint32_t w = (t.x & 0xffu) | (t.x >> 8 & 0xff00u) | (t.y << 16 & 0xff0000u) | (t.y << 8 & 0xff000000u);
-						tw_st32(c_lut + ((uint32_t)k << 2), (int)w);
-					}
-					const uint32_t x_none = (uint32_t)g.a[c.base].x - (uint32_t)maxx - 1u;    // "no anchor here" in the x+1 encoding
-					for (int k = hl; k < 128; k += 32) tw_st64(((uint32_t)k << 4 | c_8h) + TW_XY, x_none, 0u);
-					for (int k = hl; k < 65; k += 32) tw_st32(mkbase + ((uint32_t)k << 2), -1);
-					wave_mem_fence();
-					c.x_carry = 0;
-					u.slow = 0;
-				}
-				// the tile: 32 anchors, one 16-byte load per lane
-				const int i_lane = c.tile0 + hl;
-				const bool have = i_lane < c.room;
-				ulonglong2 an = make_ulonglong2(0, 0);
-				if (have) an = g.a[c.base + i_lane];
+		bool lane_retired = false;
+		for (int hs = 0; hs < 2; ++hs) {
+			if (((svc >> (32 * hs)) & 1ull) == 0) continue;
+			if (h != hs) continue;
+			const uint32_t sa = TW_ST + 64u * (uint32_t)hs;
+			const tw_u32x4 cw0 = tw_ld128(sa), cw1 = tw_ld128(sa + 16u);
+			const tw_u32x2 cw2 = tw_ld64(sa + 32u);
+			int64_t c_next = (int64_t)((uint64_t)TW_UNI(cw0.y) << 32 | TW_UNI(cw0.x));
+			int64_t c_base = (int64_t)((uint64_t)TW_UNI(cw0.w) << 32 | TW_UNI(cw0.z));
+			uint64_t c_xcarry = (uint64_t)TW_UNI(cw1.y) << 32 | TW_UNI(cw1.x);
+			int c_rel0 = (int)TW_UNI(cw1.z), c_room = (int)TW_UNI(cw1.w), c_read = (int)TW_UNI(cw2.x), c_tile0 = (int)TW_UNI(cw2.y);
+			const int cnt_prev = (int)TW_UNI((u.pend - curbase) >> 4);   // anchors of the tile that has just been scored
+			const int tile_prev = c_tile0, rel0_prev = c_rel0;
+			const int64_t base_prev = c_base;
+			bool live = true;
+
+			// takes a tile's anchors (one per lane, raw mm128_t) into the half's LDS: where the unit ends (first gap > max_dist_x,
+			// chain.c:252), XY ring (the anchors as predecessors), CUR (as the current anchor); requests the tile after it.
+			// Returns the anchors the tile holds (0: the unit ended exactly at its start).
+			auto take_tile = [&](ulonglong2 an) -> int {
+				const int i_lane = c_tile0 + hl;
+				const bool have = i_lane < c_room;
 				uint64_t xp;
 				{
 					uint32_t lo = (uint32_t)wave_shift_up1((int)(uint32_t)an.x, 0), hi = (uint32_t)wave_shift_up1((int)(uint32_t)(an.x >> 32), 0);
-					if (hl == 0) { lo = (uint32_t)c.x_carry; hi = (uint32_t)(c.x_carry >> 32); }
+					if (hl == 0) { lo = (uint32_t)c_xcarry; hi = (uint32_t)(c_xcarry >> 32); }
 					xp = (uint64_t)hi << 32 | lo;
 				}
-				const bool stop = !have || (i_lane > 0 && an.x - xp > maxx);   // the unit ends at the first gap > max_dist_x (chain.c:252)
-				const uint64_t stop_m = __builtin_amdgcn_ballot_w64(stop) & my_half;
-				const uint32_t stop_h = hi_half ? (uint32_t)(stop_m >> 32) : (uint32_t)stop_m;
+				const bool stop = !have || (i_lane > 0 && an.x - xp > maxx);
+				const uint64_t stop_m = __builtin_amdgcn_ballot_w64(stop);                      // (only this half's lanes are active)
+				const uint32_t stop_h = hs ? (uint32_t)(stop_m >> 32) : (uint32_t)stop_m;
 				const int cnt = stop_h ? __builtin_ctz(stop_h) : 32;
-				{
-					const int last = (h << 5) + 31;
-					const uint32_t clo = (uint32_t)__builtin_amdgcn_ds_bpermute(last << 2, (int)(uint32_t)an.x);
-					const uint32_t chi = (uint32_t)__builtin_amdgcn_ds_bpermute(last << 2, (int)(uint32_t)(an.x >> 32));
-					c.x_carry = (uint64_t)chi << 32 | clo;
-				}
-				fresh_unit = false;
-				cnt_prev = cnt;
+				c_xcarry = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(an.x >> 32), 32 * hs + 31) << 32 |
+				           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)an.x, 32 * hs + 31);
 				u.pc = curbase; u.pend = curbase + ((uint32_t)cnt << 4);
-				if (cnt == 0) continue;                                      // the unit ended exactly on the boundary: unit_done next round
-				// publish the tile: XY ring (for its anchors as predecessors) and CUR (for them as the current anchor)
+				if (cnt == 0) return 0;
 				wave_mem_fence();
 				if (hl < cnt) {
 					const int sp = span_of_hi((uint32_t)(an.y >> 32));
@@ -405,18 +336,129 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 					tw_st128(curbase + ((uint32_t)hl << 4), (uint32_t)an.x, (uint32_t)an.y, (uint32_t)(sp - 1), (uint32_t)sp);
 				}
 				wave_mem_fence();
-				need = false;
+				// the tile after this one: the load is issued now and read at the half's next service, 32 anchors of work later
+				an_nx = make_ulonglong2(0, 0);
+				if (cnt == 32 && i_lane + 32 < c_room) an_nx = g.a[c_base + i_lane + 32];
+				return cnt;
+			};
+
+			// ---- the unit goes on?
+			bool goes_on = cnt_prev == 32 && c_tile0 + 32 < c_room;
+			if (goes_on && c_tile0 + 32 >= 64 && (int)TW_UNI(u.slow) * 8 > c_tile0 + 32) {
+				// a unit that keeps needing second chunks (more than one anchor in eight) is cheaper in k_chain_units: hand the rest
+				// of it -- that is, all of it, from scratch -- over
+				if (hl == 0) { Unit un; un.start = c_base; un.read = c_read; un.len = c_room; g.left[atomicAdd(g.left_cnt, 1u)] = un; }
+				goes_on = false;
+			}
+			if (goes_on) {
+				c_tile0 += 32;
+				if (take_tile(an_nx) == 0) goes_on = false;                // it ended exactly on the boundary
+			}
+			// ---- flush the finished tile
+			TW_STAMP(const unsigned long long tf0 = g.stamp ? TW_NOW() : 0;)
+			if (cnt_prev > 0) {
+				const int i_lane = tile_prev + hl;                           // this lane's anchor of the finished tile
+				const bool have = hl < cnt_prev;
+				const int64_t gi = base_prev + i_lane;
+				int fi = 0, p4 = -4;
+				if (have) {
+					const tw_u32x2 pf = tw_ld64((((uint32_t)i_lane & 63u) << 4 | c_8h) + TW_PF);
+					p4 = (int)pf.x; fi = (int)pf.y;
+				}
+				const int pi = p4 >> 2;                                      // unit-relative predecessor, -1 = none
+				int val = fi, ptr = have ? pi : -1;
+				const bool ext = ptr >= 0 && ptr < tile_prev;                // predecessor in an earlier tile: its v is final, in the V ring
+				int vext = 0;
+				if (ext) {
+					vext = tw_ld32((((uint32_t)ptr & 63u) << 3 | (uint32_t)h << 2) + TW_V);
+					val = max(val, vext & 0x7fffffff);
+					ptr = -1;
+				}
+				const bool ext_self = ext && vext < 0;                       // (bit 31 of a V entry: the anchor was emitted at its own step)
+				for (int r = 0; r < 5; ++r) {                                // v[i] = max(f[i], v[p[i]]) (chain.c:284) by pointer doubling over the tile
+					if (__builtin_amdgcn_ballot_w64(ptr >= tile_prev) == 0) break;
+					const int src = ((ptr >= tile_prev ? ptr - tile_prev : hl) + (hs << 5)) << 2;
+					const int pv = __builtin_amdgcn_ds_bpermute(src, val);
+					const int pp = __builtin_amdgcn_ds_bpermute(src, ptr);
+					if (ptr >= tile_prev) { val = max(val, pv); ptr = pp; }
+				}
+				const bool self = val >= g.par.min_sc || pi >= 0;            // emitted at its own step (chain.c:304)
+				// is the predecessor emitted at its own step?  in-tile predecessors: ask their lane
+				const int srcp = ((pi >= tile_prev ? pi - tile_prev : hl) + (hs << 5)) << 2;
+				const int pself_in = __builtin_amdgcn_ds_bpermute(srcp, self ? 1 : 0);
+				const bool pred_self = ext ? ext_self : pself_in != 0;
+				wave_mem_fence();
+				if (have) tw_st32((((uint32_t)i_lane & 63u) << 3 | (uint32_t)h << 2) + TW_V, val | (self ? INT_MIN : 0));
+				wave_mem_fence();
+				// (first_child[] of the whole batch is NO_CHILD when this kernel starts -- one memset by the host -- so that no tile has
+				// to store it and wait for the store before its children's atomics)
+				if (have) {
+					g.f[gi] = fi;
+					g.p[gi] = pi < 0 ? -1 : pi + rel0_prev;
+					g.v[gi] = val;
+					int maybe_first = 0;
+					if (pi >= 0 && !pred_self) { atomicMin(&g.first_child[base_prev + pi], rel0_prev + i_lane); maybe_first = 4; }
+					g.flags[gi] = (uint8_t)((self ? 2 : 0) | maybe_first | (val >= g.par.min_sc ? 8 : 0) | (fi < val ? 16 : 0));
+				}
+			}
+			TW_STAMP(if (g.stamp) st_flush += TW_NOW() - tf0;)
+			TW_STAMP(const unsigned long long tu0 = g.stamp ? TW_NOW() : 0;)
+			TW_STAMP(if (g.stamp && !goes_on) ++st_n_unit;)
+			// ---- the unit is over: the half's next unit (units that are not for this kernel are handed over), its LDS, its first tile
+			while (!goes_on && live) {
+				Unit un;
+				for (;;) {
+					uint32_t nx = (uint32_t)c_next, ne = (uint32_t)((uint64_t)c_next >> 32);
+					if (nx >= ne) {
+						// the chunk is used up: the next TW_QCH units nobody has taken (the list is longest first, so the two halves of a
+						// wave, and all waves, work on units of similar length at any time and run out of work together)
+						uint32_t q0 = 0;
+						if (hl == 0) q0 = atomicAdd(g.queue, (unsigned int)TW_QCH);
+						nx = TW_UNI(q0); ne = nx + TW_QCH;
+					}
+					if ((int64_t)nx >= n_units) { c_next = (int64_t)((uint64_t)ne << 32 | nx); live = false; break; }
+					un = g.units[nx];
+					c_next = (int64_t)((uint64_t)ne << 32 | (nx + 1u));
+					const unsigned long long sq = g.sumq[un.read];
+					const bool general = !params_ok || (sq & (SUMQ_SEG_FLAG | SUMQ_LUT16_FLAG)) || g.par.n_segs > 1;
+					if (!general) break;
+					if (hl == 0) g.left[atomicAdd(g.left_cnt, 1u)] = un;       // not for this kernel: hand the unit over
+				}
+				if (!live) { u.pc = curbase; u.pend = curbase; break; }
+				c_base = un.start; c_rel0 = (int)(un.start - g.off[un.read]); c_room = un.len; c_read = un.read; c_tile0 = 0;
+				// LDS of the half for a new unit: marks never match, every XY slot fails the window test, the read's table (as bytes)
+				const uint2 *src = (const uint2*)(g.lut + (int64_t)c_read * g.lut_stride);
+				ulonglong2 an = make_ulonglong2(0, 0);
+				if (hl < c_room) an = g.a[c_base + hl];                        // the unit's first tile
+				wave_mem_fence();
+				for (int k = hl; k * 4 <= g.par.bw; k += 32) {                 // lut_stride is a multiple of 8 entries: whole uint2 loads
+					const uint2 t = src[k];
+					const uint32_t w = (t.x & 0xffu) | (t.x >> 8 & 0xff00u) | (t.y << 16 & 0xff0000u) | (t.y << 8 & 0xff000000u);
+					tw_st32(c_lut + ((uint32_t)k << 2), (int)w);
+				}
+				const uint32_t x_none = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)an.x, 32 * hs) - (uint32_t)maxx - 1u;   // "no anchor here" (x+1 encoding)
+				for (int k = hl; k < 128; k += 32) tw_st64(((uint32_t)k << 4 | c_8h) + TW_XY, x_none, 0u);
+				for (int k = hl; k < 65; k += 32) tw_st32(mkbase + ((uint32_t)k << 2), -1);
+				wave_mem_fence();
+				c_xcarry = 0;
+				u.slow = 0;
+				if (take_tile(an) > 0) goes_on = true;                         // (a unit has at least two anchors: always)
+			}
+			TW_STAMP(if (g.stamp) st_unit += TW_NOW() - tu0;)
+			// ---- the tile's first anchor becomes current
+			if (live) {
+				const uint32_t i = (uint32_t)c_tile0;
+				u.maxj4 = -4; u.nskip = 0; u.kb4 = 0;
+				u.S = (i - 1u) << 4 | c_8h; u.m4 = ((i - 1u) << 2) + mkbase;
+			} else lane_retired = true;
+			if (hl == 0) {
+				tw_st128(sa, (uint32_t)c_next, (uint32_t)((uint64_t)c_next >> 32), (uint32_t)c_base, (uint32_t)((uint64_t)c_base >> 32));
+				tw_st128(sa + 16u, (uint32_t)c_xcarry, (uint32_t)(c_xcarry >> 32), (uint32_t)c_rel0, (uint32_t)c_room);
+				tw_st64(sa + 32u, (uint32_t)c_read, (uint32_t)c_tile0);
 			}
 		}
-		// ---- (d) the tile's first anchor becomes current
-		if (mine && live) {
-			const uint32_t i = (uint32_t)c.tile0;
-			u.maxj4 = -4; u.nskip = 0; u.kb4 = 0;
-			u.S = (i - 1u) << 4 | c_8h; u.m4 = ((i - 1u) << 2) + mkbase;
-		}
-		if (mine && hl == 0) TW_COLD = c;
 		wave_mem_fence();
-		live_m &= ~__builtin_amdgcn_ballot_w64(mine && !live);
+		live_m &= ~__builtin_amdgcn_ballot_w64(lane_retired);
 		contm &= ~svc;
 	};
 
@@ -457,6 +499,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 		return 0;
 	};
 
+	TW_STAMP(if (g.stamp) st_t0 = TW_NOW();)
 	service(~0ull);
 	bool force_general = false;
 	// ======================================================================================== main loop: one chunk pass per trip
@@ -517,16 +560,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				u.m4 += 4u; u.S = S1;
 				u.pc += 16u;
 				tile = TW_SGE(u.pc, u.pend);
+				TW_STAMP(if (g.stamp) ++st_n_fast;)
 				if (__builtin_expect(tile != 0, 0)) break;
 				wave_mem_fence();
 			}
 			if (!force_general && tile == 0) {
 				// a half wants its second chunk.  n_skip after the first: #B, as no A lane follows a B lane
+				TW_STAMP(const unsigned long long ts = g.stamp ? TW_NOW() : 0;)
 				svc = slow_tail(tw_smear_halves(X), a_cur + TW_PF, cB + (int)__builtin_amdgcn_inverse_ballot_w64(B));
+				TW_STAMP(if (g.stamp) st_slow += TW_NOW() - ts;)
 			}
 		} else {
 			// ------------------------------------------------------------ general pass: second chunks, idle halves, interleaved walks
 			force_general = false;
+			TW_STAMP(const unsigned long long tg0 = g.stamp ? TW_NOW() : 0;)
+			TW_STAMP(if (g.stamp) ++st_n_general;)
 			const uint32_t t0 = u.S - L16;
 			const tw_u32x2 xy = tw_ld64((t0 & 0x7f8u) + TW_XY);
 			const tw_u32x2 pf = tw_ld64((t0 & 0x3f8u) + TW_PF);
@@ -576,11 +624,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 			}
 			const uint64_t D = tw_smear_halves(brk | (OUT & TW_HI31) | ~live_m);   // idle halves count as done
 			svc = slow_tail(D, a_cur, nskip_after);
+			TW_STAMP(if (g.stamp) st_general += TW_NOW() - tg0;)
 		}
 		// ---------------------------------------------------------------- tile exhausted (or unit handed over): flush, next tile / unit
 		svc |= tw_smear_halves(TW_SGE(u.pc, u.pend) & live_m & ~contm);
-		if (__builtin_expect(svc != 0, 0)) service(svc & live_m);
+		if (__builtin_expect(svc != 0, 0)) {
+			TW_STAMP(const unsigned long long ts = g.stamp ? TW_NOW() : 0;)
+			service(svc & live_m);
+			TW_STAMP(if (g.stamp) { st_service += TW_NOW() - ts; ++st_n_service; })
+		}
 	}
+	TW_STAMP(if (g.stamp && lane == 0) {
+		unsigned long long *o = g.stamp + 8 * (size_t)blockIdx.x;
+		o[0] = TW_NOW() - st_t0; o[1] = st_service; o[2] = st_flush; o[3] = st_unit; o[4] = st_n_service; o[5] = st_n_fast; o[6] = st_n_unit; o[7] = 1;
+		(void)st_slow; (void)st_general; (void)st_n_general;
+	})
 #undef TW_COLD
 }
 
@@ -592,13 +650,28 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
                              int32_t *d_first_child, uint8_t *d_flags, Unit *d_left, unsigned int *d_left_cnt, int force_left, int64_t total)
 {
 	if (max_units <= 0) return hipSuccess;
-	int64_t blocks = (max_units + 1) / 2;
-	const int64_t cap = 256LL * 24 * 16;
+	// persistent waves: as many as the chip holds at the kernel's occupancy (6 per SIMD), each half taking units from a queue
+	int dev = 0, cus = 256;
+	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	int64_t blocks = (max_units + 2 * TW_QCH - 1) / (2 * TW_QCH);
+	const int64_t cap = (int64_t)cus * 24;
 	if (blocks > cap) blocks = cap;
+	if (blocks < 1) blocks = 1;
+	{
+		const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)(d_left_cnt + 1), (int)(2 * TW_QCH * blocks), 1, st);   // the queue starts behind the first chunks
+		if (e != hipSuccess) return e;
+	}
 	TwinArgs g;
 	g.par = par; g.off = d_off; g.a = (const ulonglong2*)d_a; g.sumq = d_sumq; g.lut = d_lut; g.lut_stride = lut_stride;
 	g.units = d_units; g.counters = d_counters; g.f = d_f; g.p = d_p; g.v = d_v; g.first_child = d_first_child; g.flags = d_flags;
-	g.left = d_left; g.left_cnt = d_left_cnt; g.force_left = force_left; g.total = total;
+	g.left = d_left; g.left_cnt = d_left_cnt; g.queue = d_left_cnt + 1; g.force_left = force_left; g.total = total;
+	// diagnostic: CHAINDP_TWIN_STAMP=1 makes the kernel stamp where its waves' time goes (s_memtime: shader-clock ticks) and this
+	// function print the averages -- it synchronises, so never set it in a timed run
+	static unsigned long long *d_stamp = nullptr;
+	const bool stamp = getenv("CHAINDP_TWIN_STAMP") != nullptr;
+	if (stamp && !d_stamp && hipMalloc((void**)&d_stamp, (size_t)cap * 64) != hipSuccess) d_stamp = nullptr;
+	g.stamp = stamp ? d_stamp : nullptr;
+	if (g.stamp) (void)hipMemsetAsync(d_stamp, 0, (size_t)blocks * 64, st);
 	{
 		hipFuncAttributes fa;                                        // LDS is addressed by raw byte offsets from 0: no static LDS may sit in front
 		const void *fn = par.max_dist_y >= par.max_dist_x ? (const void*)k_chain_twin<true> : (const void*)k_chain_twin<false>;
@@ -608,6 +681,16 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
 	}
 	if (par.max_dist_y >= par.max_dist_x) hipLaunchKernelGGL(k_chain_twin<true>, dim3((unsigned)blocks), dim3(64), TW_LDS_BYTES, st, g);
 	else hipLaunchKernelGGL(k_chain_twin<false>, dim3((unsigned)blocks), dim3(64), TW_LDS_BYTES, st, g);
+	if (g.stamp) {
+		std::vector<unsigned long long> hb((size_t)blocks * 8);
+		if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hb.data(), d_stamp, hb.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+			double tot = 0, svc = 0, slow = 0, gen = 0, nsvc = 0, nfast = 0, ngen = 0, nb = 0;
+			for (int64_t b = 0; b < blocks; ++b) if (hb[(size_t)b * 8 + 7]) { tot += hb[b * 8]; svc += hb[b * 8 + 1]; slow += hb[b * 8 + 2]; gen += hb[b * 8 + 3]; nsvc += hb[b * 8 + 4]; nfast += hb[b * 8 + 5]; ngen += hb[b * 8 + 6]; ++nb; }
+			fprintf(stderr, "[twin stamp] %.0f waves, %.0f ticks each: service %.1f%% (%.0f calls, %.0f ticks each), of it flush %.1f%%, unit switch %.1f%% (%.0f switches, %.0f ticks each), "
+			                "passes %.0f (%.0f ticks each, everything else included)\n", nb, tot / nb, 100.0 * svc / tot, nsvc, svc / (nsvc > 0 ? nsvc : 1),
+			        100.0 * slow / tot, 100.0 * gen / tot, ngen, gen / (ngen > 0 ? ngen : 1), nfast, (tot - svc) / (nfast > 0 ? nfast : 1));
+		}
+	}
 	return hipGetLastError();
 }
 
