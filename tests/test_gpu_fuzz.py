@@ -65,7 +65,8 @@ def test_random_case(dev, k, par_kw, gen_kw, ring, general, n_reads, min_cnt):
     n_segs = None
     if par.n_segs > 1 and k % 2:                      # per-read n_segs as in collect_task_t
         n_segs = (np.arange(n_reads) % par.n_segs + 1).astype(np.int32)
-    dev.set_ring(ring); dev.set_variant(general)
+    # general: k_chain_units' 64-bit variant; otherwise the table-driven code, alternately two units per wave (+ hand-over) and one
+    dev.set_ring(ring); dev.set_variant(1 if general else (2 if k % 2 else 0))
     try:
         f, p, v = dev.chain_batch(par, off, a, n_segs=n_segs)
         of, op, ov, _ = ol.oracle_batch(par, off, a, n_segs=n_segs, threads=4)

@@ -17,11 +17,12 @@ def dev():
         yield d
 
 
-@pytest.mark.parametrize("ring,general", [(128, False), (256, False), (512, False), (128, True), (256, True)])
+@pytest.mark.parametrize("ring,general", [(128, 0), (256, 0), (512, 0), (128, 1), (256, 1), (128, 2), (256, 2), (512, 2)])
 @pytest.mark.parametrize("name", golden_names())
 def test_golden_fixture_bit_exact(dev, name, ring, general):
-    """Every fixture through both variants of the DP kernel (table-driven fast path / general 64-bit path)
-    and every LDS ring size (small rings push the long scans onto the deep, global-memory path)."""
+    """Every fixture through the three ways the DP can run -- 0: two units per wave (k_chain_twin) with k_chain_units for what it
+    hands over, 1: k_chain_units' general 64-bit variant, 2: k_chain_units alone, table-driven where it applies -- and every
+    LDS ring size of k_chain_units (small rings push the long scans onto the deep, global-memory path)."""
     g = load_golden(name)
     par = params_from(g["params"])
     dev.set_ring(ring)
@@ -53,10 +54,11 @@ CASES = [  # generator, generator overrides, DP preset, DP overrides, reads, per
 ]
 
 
+@pytest.mark.parametrize("variant", [0, 2], ids=["two_per_wave", "one_per_wave"])
 @pytest.mark.parametrize("gen,gen_over,preset,par_over,n_reads,per_read", CASES)
-def test_seeded_batches_match_oracle(dev, gen, gen_over, preset, par_over, n_reads, per_read):
+def test_seeded_batches_match_oracle(dev, gen, gen_over, preset, par_over, n_reads, per_read, variant):
     dev.set_ring(128)
-    dev.set_variant(False)
+    dev.set_variant(variant)
     par = P.preset(preset, **par_over)
     off, a = ag.generate(gen, n_reads=n_reads, seed=1234, **gen_over)
     n_segs = None
