@@ -318,6 +318,18 @@ class Device:
         self._lib.chaindp_debug_leftover.argtypes = [C.c_void_p]
         return int(self._lib.chaindp_debug_leftover(self._ctx))
 
+    def deep_units(self):
+        """Units the one-per-wave kernel handed over to its large-ring launch in the last run (test / tuning hook)."""
+        self._lib.chaindp_debug_deep_units.restype = C.c_int64
+        self._lib.chaindp_debug_deep_units.argtypes = [C.c_void_p]
+        return int(self._lib.chaindp_debug_deep_units(self._ctx))
+
+    def set_deep_handover(self, on=True):
+        """Test hook: False keeps every unit in the launch that took it (small rings then serve long scans from HBM/L2)."""
+        self._lib.chaindp_debug_set_deep_handover.restype = C.c_int
+        self._lib.chaindp_debug_set_deep_handover.argtypes = [C.c_void_p, C.c_int]
+        self._check(self._lib.chaindp_debug_set_deep_handover(self._ctx, int(bool(on))))
+
     def stats(self):
         st = (C.c_int64 * 4)()
         self._check(self._lib.chaindp_get_stats(self._ctx, st))

@@ -37,7 +37,9 @@ struct chaindp_ctx {
 	unsigned long long *d_sumq = nullptr;
 	Unit *d_units = nullptr;
 	Unit *d_left = nullptr;               // units the two-per-wave kernel hands over to k_chain_units
-	unsigned long long *d_left_cnt = nullptr;
+	unsigned long long *d_left_cnt = nullptr;   // [0] handed-over count | the twin kernel's queue << 32; [1] count of d_deep
+	Unit *d_deep = nullptr;               // units k_chain_units hands over to its large-ring launch (scans that keep reaching past the ring)
+	bool deep_handover = true;            // CHAINDP_NO_DEEP_HANDOVER (diagnostic / A-B): every unit stays in the launch that took it
 	int variant = 0;                      // 0: k_chain_twin + k_chain_units for the rest; 1: k_chain_units, general variant; 2: k_chain_units only
 	unsigned long long *d_counters = nullptr;
 	chaindp::PrepassScratch pre = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -129,7 +131,7 @@ extern "C" void chaindp_destroy(chaindp_ctx_t *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	for (auto &es : ctx->pending) for (int k = 0; k < es.n; ++k) (void)hipEventDestroy(es.e[k]);
 	void *bufs[] = {ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_sumq, ctx->d_units,
-	                ctx->d_counters, ctx->d_left, ctx->d_left_cnt, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->pre.units_tmp, ctx->pre.hist, ctx->pre.block_reads, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->cmp.sub, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
+	                ctx->d_counters, ctx->d_left, ctx->d_left_cnt, ctx->d_deep, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->pre.units_tmp, ctx->pre.hist, ctx->pre.block_reads, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->cmp.sub, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
 	for (void *b : bufs) if (b) (void)hipFree(b);
 	for (void *b : ctx->bot_allocs) if (b) (void)hipFree(b);
 	void *sbufs[] = {ctx->seed.kept, ctx->seed.used, ctx->seed.src, ctx->seed.mstate, ctx->seed.tile_tmp, ctx->seed.totals, ctx->seed.stacks,
@@ -166,7 +168,8 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_units, (na / 2 + 1) * sizeof(Unit));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 2 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left, (na / 2 + 1) * sizeof(Unit));
-	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left_cnt, sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left_cnt, 2 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_deep, (na / 128 + 2) * sizeof(Unit));   // a unit is handed over after 128 anchors at the earliest
 	size_t flags_bytes0 = 0, cblocks_bytes0 = 0;
 	chaindp::compact_scratch_bytes(ctx->cap_anchors, &flags_bytes0, &cblocks_bytes0);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_first_child, na * 4);
@@ -180,6 +183,7 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.hist, 2 * 128 * sizeof(unsigned int));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.block_reads, blocks_bytes);   // 8 B per block, like the counters
 	ctx->cmp.block_reads = ctx->pre.block_reads;
+	ctx->deep_handover = getenv("CHAINDP_NO_DEEP_HANDOVER") == nullptr;
 	if (e != hipSuccess) {
 		g_create_error = std::string("chaindp_create: ") + hipGetErrorString(e);
 		chaindp_destroy(ctx);
@@ -191,7 +195,7 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 extern "C" int chaindp_set_ring(chaindp_ctx_t *ctx, int ring)
 {
 	if (!ctx) return CHAINDP_ERR_ARG;
-	if (ring != 128 && ring != 256 && ring != 512) { ctx->err = "ring must be 128, 256 or 512"; return CHAINDP_ERR_ARG; }
+	if (ring != 128 && ring != 256 && ring != 512 && ring != 1024) { ctx->err = "ring must be 128, 256, 512 or 1024"; return CHAINDP_ERR_ARG; }
 	ctx->ring = ring;
 	return CHAINDP_OK;
 }
@@ -254,9 +258,11 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		HIP_TRY(ctx, hipMemsetAsync(ctx->d_tg, 0, (size_t)ctx->cap_anchors * 8, st));
 		ctx->epoch = 1;
 	}
+	HIP_TRY(ctx, hipMemsetAsync(ctx->d_left_cnt, 0, 2 * sizeof(unsigned long long), st));
+	Unit *const deep = ctx->deep_handover ? ctx->d_deep : nullptr;
+	unsigned int *const deep_cnt = (unsigned int*)(ctx->d_left_cnt + 1);
 	if (ctx->variant == 0 && lut && d_n_segs == nullptr) {
 		// ordinary units two per wave; what that kernel hands over (and nothing else) goes through k_chain_units
-		HIP_TRY(ctx, hipMemsetAsync(ctx->d_left_cnt, 0, sizeof(unsigned long long), st));
 		if (total > 0) HIP_TRY(ctx, hipMemsetAsync(ctx->d_first_child, 0x7f, (size_t)total * 4, st));   // NO_CHILD everywhere (chaindp_wave.h)
 		HIP_TRY(ctx, chaindp::launch_chain_twin(st, q, total / 2, d_off, d_a, ctx->d_sumq, lut, lut_stride, ctx->d_units, ctx->d_counters,
 		                                        d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->d_left, (unsigned int*)ctx->d_left_cnt,
@@ -264,10 +270,15 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		const int64_t left_grid = total / 2 < 32768 ? total / 2 : 32768;
 		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, left_grid, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_left,
 		                                   ctx->d_left_cnt, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
-		                                   ctx->d_units, ctx->d_counters));
+		                                   ctx->d_units, ctx->d_counters, deep, deep_cnt));
 	} else
 		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, total / 2, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_units,
-		                                   ctx->d_counters, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags));
+		                                   ctx->d_counters, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
+		                                   nullptr, nullptr, deep, deep_cnt));
+	// units whose scans kept reaching past the ring (dense repeats): redone with the large ring
+	if (deep && lut && ctx->ring < 1024)
+		HIP_TRY(ctx, chaindp::launch_chain_deep(st, q, total / 128 + 1, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_deep,
+		                                        ctx->d_left_cnt + 1, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags));
 	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[2], st)); ctx->pending.push_back(es); }
 	ctx->stats[2] = total; ctx->stats[3] = n_reads;
 	return CHAINDP_OK;
@@ -569,6 +580,25 @@ extern "C" int64_t chaindp_debug_leftover(chaindp_ctx_t *ctx)
 	unsigned long long c = 0;
 	if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
 	    hipMemcpy(&c, ctx->d_left_cnt, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	return (int64_t)(uint32_t)c;
+}
+
+// test hook (not in the public header): 0 keeps every unit in the launch that took it (the deep path of the small rings stays
+// covered by the parity tests), 1 (default) hands units whose scans keep reaching past the ring to the large-ring launch
+extern "C" int chaindp_debug_set_deep_handover(chaindp_ctx_t *ctx, int on)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	ctx->deep_handover = on != 0;
+	return CHAINDP_OK;
+}
+
+// test hook (not in the public header): units k_chain_units handed over to its large-ring launch in the last run
+extern "C" int64_t chaindp_debug_deep_units(chaindp_ctx_t *ctx)
+{
+	if (!ctx || !ctx->d_left_cnt) return -1;
+	unsigned long long c = 0;
+	if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+	    hipMemcpy(&c, ctx->d_left_cnt + 1, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) return -1;
 	return (int64_t)(uint32_t)c;
 }
 

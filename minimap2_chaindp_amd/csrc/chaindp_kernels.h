@@ -49,7 +49,14 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
                         const int32_t *d_n_segs, const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
                         const Unit *d_units, const unsigned long long *d_counters,
                         int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags,
-                        const Unit *d_units_all = nullptr, const unsigned long long *d_counters_all = nullptr);
+                        const Unit *d_units_all = nullptr, const unsigned long long *d_counters_all = nullptr,
+                        Unit *d_deep = nullptr, unsigned int *d_deep_cnt = nullptr);
+// Units whose scans keep reaching past the ring are appended to d_deep / *d_deep_cnt by the launch above (when given) and run
+// by this one: the same kernel with a ring of 1024 anchors.  The low 32 bits of *d_deep_cnt are the count.
+hipError_t launch_chain_deep(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
+                             const int32_t *d_n_segs, const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
+                             const Unit *d_deep, const unsigned long long *d_deep_cnt,
+                             int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags);
 
 // Two units per wave, 32 lanes each (chaindp_twin.hip): takes the ordinary units, appends the others (general-variant reads,
 // scans that reach beyond 64 predecessors) to d_left / *d_left_cnt (low 32 bits = count), which launch_chain then runs.

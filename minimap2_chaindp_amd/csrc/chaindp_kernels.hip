@@ -43,6 +43,16 @@ __device__ __forceinline__ int pair_score(int sc0, int dd, int dr, int dq, bool 
 	return sc0 - (lin + (lg >> 1));
 }
 
+// scans past the ring after which a unit is handed to the launch with the large ring
+#define CHAINDP_DEEP_HANDOVER 8
+#ifndef CHAINDP_DEEP_RING
+#define CHAINDP_DEEP_RING 1024
+#endif
+// deep chunks (predecessors older than the ring, from HBM/L2) evaluated per pair of round trips
+#ifndef CHAINDP_DEEP_GROUP
+#define CHAINDP_DEEP_GROUP 8
+#endif
+
 // Per-unit constants and the LDS carve-up.  Ring entry k (16 B): x.lo, qpos, f, p (unit-relative);
 // side arrays: mark tag t[], v[], and (general variant only) x.hi[], y.hi[]; then the read's cost table.
 // During step i the ring holds anchors i-RING .. i-1 (entry i is written at the end of step i).
@@ -62,9 +72,14 @@ struct UnitCtx {
 	int64_t base;
 	uint64_t maxx;
 	double avgd;
-	int rel0, lane;
+	int rel0, lane, read;
 	int mdx, mdy, mdq, bw, max_skip, is_cdna;
 	bool seg_rule;
+	// units whose scans keep reaching past the ring are handed to the RING=1024 launch (launch_chain_deep): list, count,
+	// and the scans of the current unit that went past the ring so far (nullptr: this launch keeps every unit)
+	Unit *deep_list;
+	unsigned int *deep_cnt;
+	mutable int deep_n;
 };
 
 // What one chunk of 64 predecessors (lane k <-> j = i-1-kb0-k) contributes before the serial semantics are applied.
@@ -482,6 +497,57 @@ __device__ __forceinline__ bool fast_chunk(const FastK &k, uint32_t S, int jtop,
 	return (uint32_t)__builtin_amdgcn_readlane((int)m.drm1, 63) + 1u > k.M;
 }
 
+// G consecutive ring chunks (kb0, kb0 + 64, ...) of anchor i at once.  What a chunk contributes before the serial semantics
+// -- filters, scores, marks, the prefix max inside the chunk -- does not depend on the chunks in front of it, so the G
+// evaluations are issued side by side (G ring reads and table lookups in flight, one fence for all the marks) and only the
+// walks (fast_walk: a few scalar instructions each) run one after the other, each with the running max the one before left.
+// Marks written by chunks behind the break are never read.  For long scans in the large rings, where a
+// wave has its SIMD almost to itself and a chunk at a time would leave it waiting for LDS.  Returns true when the scan for
+// anchor i is complete.
+template <int RING, bool SAMEGAP, int G>
+__device__ __forceinline__ bool fast_chunk_group(const FastK &k, uint32_t xm1, uint32_t qm1, int spm1, int i, int kb0,
+                                                 int &max_f, int &max_j, int &n_skip)
+{
+	typedef FastLds<RING> L;
+	int sc[G], tj[G], excl[G];
+	uint32_t drl[G];
+	uint64_t okm[G];
+#pragma unroll
+	for (int g = 0; g < G; ++g) {
+		const uint32_t S = (uint32_t)(i - 1 - kb0 - 64 * g) << 4;
+		const FastPairs P = fast_filters<RING, SAMEGAP>(k, (S - k.L4) & (L::RB - 1u), xm1, qm1);
+		const int dqm1 = (int)P.e.y, drm1 = (int)P.drm1;
+		int sc0 = dqm1 < drm1 ? dqm1 : drm1;
+		sc0 = sc0 < spm1 ? sc0 : spm1;
+		const uint32_t di = P.dd < k.bw ? P.dd : k.bw;
+		const int scu = sc0 + (int)P.e.z + lds_load_i16(L::LUT + 2u * di);
+		okm[g] = __builtin_amdgcn_ballot_w64(P.ok);
+		sc[g] = __builtin_amdgcn_inverse_ballot_w64(okm[g]) ? scu : INT_MIN;
+		drl[g] = P.drm1;
+		const uint32_t d4 = ((uint32_t)(i - 1) << 2) - P.e.w;
+		const uint32_t dcl = d4 < 4u * RING ? d4 : 4u * RING;
+		lds_store_b32((P.ok ? dcl : k.far4) + L::T_OFF, i);
+	}
+	wave_mem_fence();
+#pragma unroll
+	for (int g = 0; g < G; ++g) {
+		tj[g] = lds_load_b32(k.trel + ((uint32_t)(kb0 + 64 * g) << 2) + L::T_OFF);
+		excl[g] = wave_excl_max_floor0(sc[g]);
+	}
+#pragma unroll
+	for (int g = 0; g < G; ++g) {
+		FastMasks m;
+		const int e = excl[g] > max_f ? excl[g] : max_f;
+		m.sc = sc[g]; m.drm1 = drl[g];
+		m.A = __builtin_amdgcn_ballot_w64(sc[g] > e);
+		m.B = okm[g] & ~m.A & __builtin_amdgcn_ballot_w64(tj[g] == i);
+		if (fast_walk(k, m, i - 1 - kb0 - 64 * g, max_f, max_j, n_skip)) return true;
+		if ((uint32_t)__builtin_amdgcn_readlane((int)drl[g], 63) + 1u > k.M) return true;
+		if (kb0 + 64 * (g + 1) >= i) return true;                  // the unit starts here: nothing older
+	}
+	return false;
+}
+
 // A deep chunk (predecessors older than the ring) of a table-driven unit: the same arithmetic as fast_masks with
 // a[j], f[j], p[j] read back from HBM/L2 and marks in the global array.  Only the window test is done in 64 bits
 // (x_i - x_j of a predecessor this old may exceed 32 bits; for a lane inside the window it does not, and every
@@ -524,6 +590,66 @@ __device__ __forceinline__ bool fast_deep_chunk(const UnitCtx &c, const FastK &k
 	return __builtin_amdgcn_ballot_w64(live) != ~0ull;             // a lane outside the window (or the unit): nothing older can matter
 }
 
+// G consecutive deep chunks at once: what fast_chunk_group does for ring chunks, for predecessors that come back from HBM/L2.
+// A deep chunk costs two dependent round trips to L2 (a/f/p of the predecessors; then the marks, which the chunk's own lanes
+// may have just written); here G chunks share them -- all their loads are in flight together, one fence, all their mark
+// reads together -- and only the walks are serial.  Chunks behind the break (or behind the unit's start) are evaluated for
+// nothing; their marks are never read.  Returns true when the scan for anchor i is complete.
+template <int RING, bool SAMEGAP, int G>
+__device__ __forceinline__ bool fast_deep_group(const UnitCtx &c, const FastK &k, uint64_t xi, uint32_t qi, int spm1, int i, int kb0,
+                                                int &max_f, int &max_j, int &n_skip)
+{
+	typedef FastLds<RING> L;
+	const unsigned long long tag = c.tg_hi | (uint32_t)i;
+	ulonglong2 aj[G];
+	int fj[G], pjr[G], sc[G], excl[G];
+	unsigned long long mk[G];
+	uint64_t okm[G], livem[G];
+	wave_global_fence();                                           // f/p of earlier tiles and the marks written so far
+#pragma unroll
+	for (int g = 0; g < G; ++g) {
+		const int j = i - 1 - kb0 - 64 * g - c.lane;
+		const int64_t gj = c.base + (j >= 0 ? j : 0);
+		aj[g] = c.a[gj]; fj[g] = c.f[gj]; pjr[g] = c.p[gj];
+	}
+#pragma unroll
+	for (int g = 0; g < G; ++g) {
+		const bool inr = i - 1 - kb0 - 64 * g - c.lane >= 0;
+		const bool live = inr && xi - aj[g].x <= c.maxx;           // chain.c:252
+		const uint32_t drm1 = (uint32_t)xi - (uint32_t)aj[g].x - 1u, dqm1 = qi - (uint32_t)aj[g].y - 1u;
+		const uint32_t dd = absdiff_u32(drm1, dqm1);
+		const uint32_t dqs = SAMEGAP ? dqm1 : __builtin_elementwise_add_sat(dqm1, k.dq_off);
+		const uint32_t m2 = drm1 > dqs ? drm1 : dqs, t = dd + k.cbw;
+		const bool ok = live && (m2 > t ? m2 : t) < k.M;           // chain.c:257-260
+		int sc0 = (int)dqm1 < (int)drm1 ? (int)dqm1 : (int)drm1;
+		sc0 = sc0 < spm1 ? sc0 : spm1;
+		const uint32_t di = dd < k.bw ? dd : k.bw;
+		const int scu = sc0 + fj[g] + lds_load_i16(L::LUT + 2u * di);
+		okm[g] = __builtin_amdgcn_ballot_w64(ok);
+		livem[g] = __builtin_amdgcn_ballot_w64(live);
+		sc[g] = __builtin_amdgcn_inverse_ballot_w64(okm[g]) ? scu : INT_MIN;
+		if (ok && pjr[g] >= 0) c.tg[c.base + (pjr[g] - c.rel0)] = tag;   // chain.c:281
+	}
+	wave_global_fence();
+#pragma unroll
+	for (int g = 0; g < G; ++g) {
+		const int j = i - 1 - kb0 - 64 * g - c.lane;
+		mk[g] = c.tg[c.base + (j >= 0 ? j : 0)];
+		excl[g] = wave_excl_max_floor0(sc[g]);
+	}
+#pragma unroll
+	for (int g = 0; g < G; ++g) {
+		FastMasks m;
+		const int e = excl[g] > max_f ? excl[g] : max_f;
+		m.sc = sc[g]; m.drm1 = 0;
+		m.A = __builtin_amdgcn_ballot_w64(sc[g] > e);
+		m.B = okm[g] & ~m.A & __builtin_amdgcn_ballot_w64(mk[g] == tag);       // (okm implies j >= 0)
+		if (fast_walk(k, m, i - 1 - kb0 - 64 * g, max_f, max_j, n_skip)) return true;
+		if (livem[g] != ~0ull) return true;                        // a lane outside the window (or the unit): nothing older can matter
+	}
+	return false;
+}
+
 // chunks beyond the first for anchor i: ring chunks, then the deep path (predecessors older than the ring, from HBM/L2)
 template <int RING, bool SAMEGAP>
 __device__ __forceinline__ void fast_more_chunks(const UnitCtx &c, const FastK &k, uint32_t xhi, int i, uint32_t xm1, uint32_t qm1,
@@ -531,12 +657,20 @@ __device__ __forceinline__ void fast_more_chunks(const UnitCtx &c, const FastK &
 {
 	typedef FastLds<RING> L;
 	const int lo4 = max((i - RING) << 2, 0);           // 4 * (oldest anchor still in the ring)
-	for (int kb0 = 64; kb0 < i; kb0 += 64) {
+	int kb0 = 64;
+	if constexpr (RING >= CHAINDP_DEEP_RING) {
+		// long scans in the large ring: four chunks at a time while four still fit the ring
+		for (; kb0 < i && kb0 + 256 <= RING; kb0 += 256)
+			if (fast_chunk_group<RING, SAMEGAP, 4>(k, xm1, qm1, spm1, i, kb0, max_f, max_j, n_skip)) return;
+	}
+	while (kb0 < i) {
 		bool done;
 		if (kb0 + 64 <= RING) {
 			done = fast_chunk<RING, SAMEGAP>(k, (uint32_t)(i - 1 - kb0) << 4, i - 1 - kb0, xm1, qm1, spm1, i, kb0, max_f, max_j, n_skip);
+			kb0 += 64;
 		} else {
 			if (kb0 == RING) {
+				++c.deep_n;
 				// first deep chunk: marks of the ring chunks whose targets are older than the ring go to the global array now
 				for (int kr = 0; kr < RING; kr += 64) {
 					const FastPairs P = fast_filters<RING, SAMEGAP>(k, ((uint32_t)((i - 1 - kr) << 4) - k.L4) & (L::RB - 1u), xm1, qm1);
@@ -544,7 +678,12 @@ __device__ __forceinline__ void fast_more_chunks(const UnitCtx &c, const FastK &
 					if (P.ok && pj4 >= 0 && pj4 < lo4) c.tg[c.base + (pj4 >> 2)] = c.tg_hi | (uint32_t)i;
 				}
 			}
-			done = fast_deep_chunk<RING, SAMEGAP>(c, k, (uint64_t)xhi << 32 | xm1, qm1, spm1, i, kb0, max_f, max_j, n_skip);
+			// (the launches with the small rings run at eight waves per SIMD and have no registers for a group; a unit that keeps
+			// coming here is handed to the large-ring launch anyway)
+			constexpr int DG = RING >= CHAINDP_DEEP_RING ? CHAINDP_DEEP_GROUP : 1;
+			if constexpr (DG > 1) done = fast_deep_group<RING, SAMEGAP, DG>(c, k, (uint64_t)xhi << 32 | xm1, qm1, spm1, i, kb0, max_f, max_j, n_skip);
+			else done = fast_deep_chunk<RING, SAMEGAP>(c, k, (uint64_t)xhi << 32 | xm1, qm1, spm1, i, kb0, max_f, max_j, n_skip);
+			kb0 += 64 * DG;
 		}
 		if (done) break;
 	}
@@ -709,11 +848,18 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 			}
 		}
 		if (cnt < 64) break;
+		// A unit whose scans keep reaching past the ring (dense repeats: the window holds hundreds of predecessors and
+		// few of them are marked) spends its time in round trips to L2.  It is handed to the launch with the large ring,
+		// which redoes it from scratch; what this wave has stored so far is what that launch stores again.
+		if (c.deep_list && c.deep_n >= CHAINDP_DEEP_HANDOVER && tile0 + 64 < room) {
+			if (lane == 0) { Unit un; un.start = c.base; un.read = c.read; un.len = (int32_t)room; c.deep_list[atomicAdd(c.deep_cnt, 1u)] = un; }
+			return;
+		}
 	}
 }
 
 template <int RING>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_chain_units(Params par, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RING >= CHAINDP_DEEP_RING ? 2 : 8, 8))) void k_chain_units(Params par, const int64_t *__restrict__ off,
                                                     const ulonglong2 *__restrict__ a, const int32_t *__restrict__ n_segs_pr,
                                                     const unsigned long long *__restrict__ sumq,
                                                     const uint16_t *__restrict__ lut, int lut_stride,
@@ -721,7 +867,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                     const unsigned long long *__restrict__ counters,
                                                     int32_t *f, int32_t *p, int32_t *v, unsigned long long *tg, uint32_t epoch,
                                                     int32_t *first_child, uint8_t *flags,
-                                                    const Unit *__restrict__ units_all, const unsigned long long *__restrict__ counters_all)
+                                                    const Unit *__restrict__ units_all, const unsigned long long *__restrict__ counters_all,
+                                                    Unit *deep_list, unsigned int *deep_cnt)
 {
 	static_assert((RING & (RING - 1)) == 0 && RING >= 128, "RING must be a power of two >= 128");
 	extern __shared__ uint4 smem[];
@@ -736,6 +883,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 	uint16_t *s_lut = (uint16_t*)(c.s_yhi + RING + 4);
 	c.s_lut = s_lut;
 	c.lane = threadIdx.x;
+	c.deep_list = RING >= CHAINDP_DEEP_RING ? nullptr : deep_list; c.deep_cnt = deep_cnt;
 	c.maxx = (uint64_t)(int64_t)par.max_dist_x;
 	c.mdx = par.max_dist_x; c.mdy = par.max_dist_y; c.bw = par.bw; c.max_skip = par.max_skip; c.is_cdna = par.is_cdna;
 	c.mdq = par.max_dist_x < par.max_dist_y ? par.max_dist_x : par.max_dist_y;   // dq > max_dist_y || dq > max_dist_x (same segment)
@@ -753,7 +901,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 		const int64_t rs = off[u.read], re = off[u.read + 1];
 		const unsigned long long sq = sumq[u.read];
 		const int n_segs = n_segs_pr ? n_segs_pr[u.read] : par.n_segs;
-		c.base = u.start;
+		c.base = u.start; c.read = u.read; c.deep_n = 0;
 		c.rel0 = (int)(u.start - rs);
 		c.avgd = (double)((float)(uint64_t)(sq & ~(SUMQ_SEG_FLAG | SUMQ_LUT16_FLAG)) / (float)(int64_t)(re - rs));   // chain.c:241: f32 divide of converted u64 and i64
 		c.seg_rule = n_segs > 1 && !par.is_cdna;                   // chain.c:261
@@ -787,7 +935,7 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
                         const int32_t *d_n_segs, const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
                         const Unit *d_units, const unsigned long long *d_counters,
                         int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags,
-                        const Unit *d_units_all, const unsigned long long *d_counters_all)
+                        const Unit *d_units_all, const unsigned long long *d_counters_all, Unit *d_deep, unsigned int *d_deep_cnt)
 {
 	if (max_units <= 0) return hipSuccess;
 	// The number of units is only known on the device (counters[0]); the grid is sized for the upper
@@ -797,21 +945,42 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
 	if (blocks > cap) blocks = cap;
 	const ulonglong2 *aa = (const ulonglong2*)d_a;
 	const size_t lds = chain_lds_bytes(ring, d_lut ? lut_stride : 0);
+	const void *fn = ring == 128 ? (const void*)k_chain_units<128> : ring == 512 ? (const void*)k_chain_units<512> :
+	                 ring == CHAINDP_DEEP_RING ? (const void*)k_chain_units<CHAINDP_DEEP_RING> : (const void*)k_chain_units<256>;
 	{
 		// the fast variant addresses LDS by raw byte offsets from 0: the kernel must have no static LDS in front of
 		// its dynamic segment
 		hipFuncAttributes fa;
-		const void *fn = ring == 128 ? (const void*)k_chain_units<128> : ring == 512 ? (const void*)k_chain_units<512> : (const void*)k_chain_units<256>;
 		const hipError_t e = hipFuncGetAttributes(&fa, fn);
 		if (e != hipSuccess) return e;
 		if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
 	}
-	switch (ring) {
-	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all); break;
-	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all); break;
-	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all); break;
+	if (lds > 64 * 1024) {
+		const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return e;
 	}
+#define CHAINDP_LAUNCH_UNITS(R) hipLaunchKernelGGL(k_chain_units<R>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, \
+		d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt)
+	switch (ring) {
+	case 128: CHAINDP_LAUNCH_UNITS(128); break;
+	case 512: CHAINDP_LAUNCH_UNITS(512); break;
+	case CHAINDP_DEEP_RING: CHAINDP_LAUNCH_UNITS(CHAINDP_DEEP_RING); break;
+	default:  CHAINDP_LAUNCH_UNITS(256); break;
+	}
+#undef CHAINDP_LAUNCH_UNITS
 	return hipGetLastError();
+}
+
+// the units the launches above handed over because their scans keep reaching past the ring: the same kernel with a ring of
+// 1024 anchors (34 KB of LDS per wave, so a wave per SIMD), one wave per unit, as many waves as the chip holds at that size
+hipError_t launch_chain_deep(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
+                             const int32_t *d_n_segs, const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
+                             const Unit *d_deep, const unsigned long long *d_deep_cnt,
+                             int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags)
+{
+	if (max_units > 2048) max_units = 2048;
+	return launch_chain(st, CHAINDP_DEEP_RING, par, max_units, d_off, d_a, d_n_segs, d_sumq, d_lut, lut_stride, d_deep, d_deep_cnt,
+	                    d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, nullptr, nullptr, nullptr, nullptr);
 }
 
 } // namespace chaindp
