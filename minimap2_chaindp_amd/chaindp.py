@@ -319,16 +319,23 @@ class Device:
         return int(self._lib.chaindp_debug_leftover(self._ctx))
 
     def deep_units(self):
-        """Units the one-per-wave kernel handed over to its large-ring launch in the last run (test / tuning hook)."""
+        """Units the one-per-wave kernel handed over to k_chain_dense in the last run (test / tuning hook)."""
         self._lib.chaindp_debug_deep_units.restype = C.c_int64
         self._lib.chaindp_debug_deep_units.argtypes = [C.c_void_p]
         return int(self._lib.chaindp_debug_deep_units(self._ctx))
 
     def set_deep_handover(self, on=True):
-        """Test hook: False keeps every unit in the launch that took it (small rings then serve long scans from HBM/L2)."""
+        """Test hook: False keeps every unit in the launch that took it (k_chain_units then serves long scans from HBM/L2)."""
         self._lib.chaindp_debug_set_deep_handover.restype = C.c_int
         self._lib.chaindp_debug_set_deep_handover.argtypes = [C.c_void_p, C.c_int]
         self._check(self._lib.chaindp_debug_set_deep_handover(self._ctx, int(bool(on))))
+
+    def set_dense_bitcap(self, bitcap=65536):
+        """Test hook: distances k_chain_dense's LDS mark bitmap covers (multiple of 512, at most 65536); marks on older
+        predecessors go through the global mark array, which a small value makes reachable for units of a few thousand anchors."""
+        self._lib.chaindp_debug_set_dense_bitcap.restype = C.c_int
+        self._lib.chaindp_debug_set_dense_bitcap.argtypes = [C.c_void_p, C.c_int]
+        self._check(self._lib.chaindp_debug_set_dense_bitcap(self._ctx, int(bitcap)))
 
     def stats(self):
         st = (C.c_int64 * 4)()

@@ -38,7 +38,8 @@ struct chaindp_ctx {
 	Unit *d_units = nullptr;
 	Unit *d_left = nullptr;               // units the two-per-wave kernel hands over to k_chain_units
 	unsigned long long *d_left_cnt = nullptr;   // [0] handed-over count | the twin kernel's queue << 32; [1] count of d_deep
-	Unit *d_deep = nullptr;               // units k_chain_units hands over to its large-ring launch (scans that keep reaching past the ring)
+	Unit *d_deep = nullptr;               // units k_chain_units hands over to its k_chain_dense (scans that keep reaching past the ring)
+	int dense_bitcap = CHAINDP_DENSE_BITCAP; // distances k_chain_dense's mark bitmap covers (test hook: smaller)
 	bool deep_handover = true;            // CHAINDP_NO_DEEP_HANDOVER (diagnostic / A-B): every unit stays in the launch that took it
 	int variant = 0;                      // 0: k_chain_twin + k_chain_units for the rest; 1: k_chain_units, general variant; 2: k_chain_units only
 	unsigned long long *d_counters = nullptr;
@@ -195,7 +196,7 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 extern "C" int chaindp_set_ring(chaindp_ctx_t *ctx, int ring)
 {
 	if (!ctx) return CHAINDP_ERR_ARG;
-	if (ring != 128 && ring != 256 && ring != 512 && ring != 1024) { ctx->err = "ring must be 128, 256, 512 or 1024"; return CHAINDP_ERR_ARG; }
+	if (ring != 128 && ring != 256 && ring != 512) { ctx->err = "ring must be 128, 256 or 512"; return CHAINDP_ERR_ARG; }
 	ctx->ring = ring;
 	return CHAINDP_OK;
 }
@@ -275,10 +276,11 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, total / 2, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_units,
 		                                   ctx->d_counters, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
 		                                   nullptr, nullptr, deep, deep_cnt));
-	// units whose scans kept reaching past the ring (dense repeats): redone with the large ring
-	if (deep && lut && ctx->ring < 1024)
-		HIP_TRY(ctx, chaindp::launch_chain_deep(st, q, total / 128 + 1, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_deep,
-		                                        ctx->d_left_cnt + 1, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags));
+	// units whose scans kept reaching past the ring (dense repeats): redone by k_chain_dense
+	if (deep && lut)
+		HIP_TRY(ctx, chaindp::launch_chain_dense(st, q, total / 128 + 1, d_off, d_a, ctx->d_sumq, lut, lut_stride, ctx->d_deep,
+		                                         ctx->d_left_cnt + 1, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
+		                                         ctx->dense_bitcap));
 	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[2], st)); ctx->pending.push_back(es); }
 	ctx->stats[2] = total; ctx->stats[3] = n_reads;
 	return CHAINDP_OK;
@@ -584,7 +586,7 @@ extern "C" int64_t chaindp_debug_leftover(chaindp_ctx_t *ctx)
 }
 
 // test hook (not in the public header): 0 keeps every unit in the launch that took it (the deep path of the small rings stays
-// covered by the parity tests), 1 (default) hands units whose scans keep reaching past the ring to the large-ring launch
+// covered by the parity tests), 1 (default) hands units whose scans keep reaching past the ring to the k_chain_dense
 extern "C" int chaindp_debug_set_deep_handover(chaindp_ctx_t *ctx, int on)
 {
 	if (!ctx) return CHAINDP_ERR_ARG;
@@ -592,7 +594,16 @@ extern "C" int chaindp_debug_set_deep_handover(chaindp_ctx_t *ctx, int on)
 	return CHAINDP_OK;
 }
 
-// test hook (not in the public header): units k_chain_units handed over to its large-ring launch in the last run
+// test hook (not in the public header): distances the mark bitmap of k_chain_dense covers (a multiple of 512); marks on
+// older predecessors go through the global mark array, which a small value makes reachable for units of a few thousand anchors
+extern "C" int chaindp_debug_set_dense_bitcap(chaindp_ctx_t *ctx, int bitcap)
+{
+	if (!ctx || bitcap < 512 || bitcap > CHAINDP_DENSE_BITCAP || bitcap % 512) return CHAINDP_ERR_ARG;
+	ctx->dense_bitcap = bitcap;
+	return CHAINDP_OK;
+}
+
+// test hook (not in the public header): units k_chain_units handed over to k_chain_dense in the last run
 extern "C" int64_t chaindp_debug_deep_units(chaindp_ctx_t *ctx)
 {
 	if (!ctx || !ctx->d_left_cnt) return -1;

@@ -51,12 +51,17 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
                         int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags,
                         const Unit *d_units_all = nullptr, const unsigned long long *d_counters_all = nullptr,
                         Unit *d_deep = nullptr, unsigned int *d_deep_cnt = nullptr);
-// Units whose scans keep reaching past the ring are appended to d_deep / *d_deep_cnt by the launch above (when given) and run
-// by this one: the same kernel with a ring of 1024 anchors.  The low 32 bits of *d_deep_cnt are the count.
-hipError_t launch_chain_deep(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
-                             const int32_t *d_n_segs, const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
-                             const Unit *d_deep, const unsigned long long *d_deep_cnt,
-                             int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags);
+// Units whose scans keep reaching past the ring (dense repeats) are appended to d_deep / *d_deep_cnt by the launch above (when
+// given) and redone by k_chain_dense (chaindp_dense.hip): one wave per unit, marks as one bit per distance in LDS, several
+// chunks of predecessors evaluated per trip to LDS / L2.  The low 32 bits of *d_deep_cnt are the count; bitcap = distances the
+// LDS mark bitmap covers (a multiple of 512, at most CHAINDP_DENSE_BITCAP; smaller values only to test the path behind it).
+#define CHAINDP_DENSE_BITCAP 65536
+#define CHAINDP_DENSE_RING 512        // its LDS ring; a unit is only handed over if 32-bit differences are exact over that span
+hipError_t launch_chain_dense(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
+                              const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
+                              const Unit *d_deep, const unsigned long long *d_deep_cnt,
+                              int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags,
+                              int bitcap);
 
 // Two units per wave, 32 lanes each (chaindp_twin.hip): takes the ordinary units, appends the others (general-variant reads,
 // scans that reach beyond 64 predecessors) to d_left / *d_left_cnt (low 32 bits = count), which launch_chain then runs.

@@ -25,6 +25,7 @@
 #include <limits.h>
 #include "chaindp_kernels.h"
 #include "chaindp_wave.h"
+#include "chaindp_fast.h"
 
 namespace chaindp {
 
@@ -43,44 +44,6 @@ __device__ __forceinline__ int pair_score(int sc0, int dd, int dr, int dq, bool 
 	return sc0 - (lin + (lg >> 1));
 }
 
-// scans past the ring after which a unit is handed to the launch with the large ring
-#define CHAINDP_DEEP_HANDOVER 8
-#ifndef CHAINDP_DEEP_RING
-#define CHAINDP_DEEP_RING 1024
-#endif
-// deep chunks (predecessors older than the ring, from HBM/L2) evaluated per pair of round trips
-#ifndef CHAINDP_DEEP_GROUP
-#define CHAINDP_DEEP_GROUP 8
-#endif
-
-// Per-unit constants and the LDS carve-up.  Ring entry k (16 B): x.lo, qpos, f, p (unit-relative);
-// side arrays: mark tag t[], v[], and (general variant only) x.hi[], y.hi[]; then the read's cost table.
-// During step i the ring holds anchors i-RING .. i-1 (entry i is written at the end of step i).
-struct UnitCtx {
-	const ulonglong2 *a;
-	int32_t *f, *p, *v;
-	unsigned long long *tg;   // global mark array (deep path): (run epoch << 32 | tag), so it is never re-initialised
-	unsigned long long tg_hi; // run epoch << 32
-	int32_t *first_child;   // compaction helper, see chaindp_compact.hip
-	uint8_t *flags;
-	int min_sc;
-	uint32_t *s_w;          // ring entries, 4 dwords each
-	int *s_t, *s_v;
-	uint32_t *s_xhi, *s_yhi;
-	const uint16_t *s_lut;
-	int *s_dummy;           // sink for lanes that have no mark to write
-	int64_t base;
-	uint64_t maxx;
-	double avgd;
-	int rel0, lane, read;
-	int mdx, mdy, mdq, bw, max_skip, is_cdna;
-	bool seg_rule;
-	// units whose scans keep reaching past the ring are handed to the RING=1024 launch (launch_chain_deep): list, count,
-	// and the scans of the current unit that went past the ring so far (nullptr: this launch keeps every unit)
-	Unit *deep_list;
-	unsigned int *deep_cnt;
-	mutable int deep_n;
-};
 
 // What one chunk of 64 predecessors (lane k <-> j = i-1-kb0-k) contributes before the serial semantics are applied.
 struct Pairs {
@@ -345,76 +308,9 @@ __device__ __forceinline__ void run_unit(const UnitCtx &c, int64_t room)
 //     floor of 0 changes nothing and saves the copy in front of the DPP chain;
 //   * v[] (chain.c:284) is not part of the recurrence at all: v[i] = max(f[i], v[p[i]]) is computed per 64-anchor
 //     tile at flush time by pointer doubling over the tile (6 rounds of ds_bpermute), not per anchor.
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-typedef int i32x2_t __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-#if defined(__HIP_DEVICE_COMPILE__)
-#define LDS_PTR(T, a) ((__attribute__((address_space(3))) T*)(a))
-#else
-#define LDS_PTR(T, a) ((T*)(uintptr_t)(a))          /* host pass of the single-source compile; never executed */
-#endif
-__device__ __forceinline__ uint4 lds_load_b128(uint32_t a) { const u32x4_t t = *LDS_PTR(const u32x4_t, a); return make_uint4(t.x, t.y, t.z, t.w); }
-__device__ __forceinline__ int2 lds_load_b64(uint32_t a) { const i32x2_t t = *LDS_PTR(const i32x2_t, a); return make_int2(t.x, t.y); }
-__device__ __forceinline__ int lds_load_b32(uint32_t a) { return *LDS_PTR(const int, a); }
-__device__ __forceinline__ int lds_load_i16(uint32_t a) { return (int)*LDS_PTR(const short, a); }
-__device__ __forceinline__ void lds_store_b32(uint32_t a, int v) { *LDS_PTR(int, a) = v; }
-__device__ __forceinline__ void lds_store_b128(uint32_t a, uint4 v) { u32x4_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *LDS_PTR(u32x4_t, a) = t; }
-
-// inclusive prefix max of max(v, 0)-floored values (see above), then the value of lane-1 (0 for lane 0)
-__device__ __forceinline__ int wave_excl_max_floor0(int v)
-{
-	v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, true));
-	v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(2), 0xf, 0xf, true));
-	v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(4), 0xf, 0xf, true));
-	v = max(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(8), 0xf, 0xf, true));
-	v = max(v, dpp_or_old<DPP_ROW_BCAST15, 0xa>(INT_MIN, v));
-	v = max(v, dpp_or_old<DPP_ROW_BCAST31, 0xc>(INT_MIN, v));
-	return __builtin_amdgcn_update_dpp(0, v, DPP_WAVE_SHR1, 0xf, 0xf, true);
-}
-
-template <int RING>
-struct FastLds {
-	static constexpr uint32_t RB = 16u * RING;            // ring entries
-	static constexpr uint32_t T_OFF = 28u * RING;         // mark tags, indexed by distance: word d-1 belongs to anchor i-d (the general
-	                                                      // variant's x.hi/y.hi space); word RING is the dummy word
-	static constexpr uint32_t V_OFF = RB + 4u * RING;     // v
-	static constexpr uint32_t DUMMY = 32u * RING;         // sink for lanes without a mark to write
-	static constexpr uint32_t LUT = 32u * RING + 16u;     // table of 1 - cost (int16)
-};
-
-struct FastK {
-	uint32_t L4;       // lane * 16
-	uint32_t far4;     // 4 * RING: offset of the dummy word behind the mark array (kept in a VGPR for v_cndmask)
-	uint32_t trel;     // 4 * lane: this lane's own mark word in chunk 0
-	uint32_t M;        // max_dist_x
-	uint32_t cbw;      // max(max_dist_x - 1 - bw, 0)
-	uint32_t dq_off;   // max_dist_x - min(max_dist_x, max_dist_y)
-	uint32_t bw;
-	int max_skip;
-	int ms0;           // max(max_skip, 0): with n_skip starting at 0 the break needs more than this many B lanes
-};
-
-struct FastPairs { uint4 e; uint32_t drm1, dd; bool ok; };
-
-// filters of chain.c:252-260 for lane k <-> slot address (S - 16k) mod ring bytes
-template <int RING, bool SAMEGAP>
-__device__ __forceinline__ FastPairs fast_filters(const FastK &k, uint32_t addr, uint32_t xm1, uint32_t qm1)
-{
-	FastPairs P;
-	P.e = lds_load_b128(addr);
-	P.drm1 = xm1 - P.e.x;
-	const uint32_t dqm1 = qm1 - P.e.y;
-	P.dd = absdiff_u32(P.drm1, dqm1);
-	const uint32_t dqs = SAMEGAP ? dqm1 : __builtin_elementwise_add_sat(dqm1, k.dq_off);
-	const uint32_t m2 = P.drm1 > dqs ? P.drm1 : dqs, t = P.dd + k.cbw;
-	P.ok = (m2 > t ? m2 : t) < k.M;
-	P.e.y = dqm1;
-	return P;
-}
 
 // One chunk of 64 ring predecessors of anchor i (lane k <-> j = jtop - k, S = 16 * jtop): scores, marks, and the
 // lane masks A ("new running max", chain.c:274) and B ("marked and not better", chain.c:277).  Straight-line code.
-struct FastMasks { uint64_t A, B; int sc; uint32_t drm1; };
 
 template <int RING, bool SAMEGAP>
 __device__ __forceinline__ FastMasks fast_masks(const FastK &k, uint32_t S, uint32_t xm1, uint32_t qm1, int spm1, int i, int kb0, int max_f)
@@ -449,42 +345,6 @@ __device__ __forceinline__ FastMasks fast_masks(const FastK &k, uint32_t S, uint
 	return m;
 }
 
-// n_skip walk when A and B lanes interleave (chain.c:276,278): A lanes x -> max(x-1,0), B lanes x -> x+1, break
-// when x > max_skip; done with a prefix min over the unclamped walk.  Returns true when the break is taken.
-__device__ __forceinline__ bool fast_walk_general(const FastK &k, const FastMasks &m, int jtop, int &max_f, int &max_j, int &n_skip)
-{
-	const bool isA = __builtin_amdgcn_inverse_ballot_w64(m.A), isB = __builtin_amdgcn_inverse_ballot_w64(m.B);
-	const int Sk = n_skip + lanes_below(m.B) + (int)isB - lanes_below(m.A) - (int)isA;
-	const int Mk = wave_scan_min(Sk);
-	const int x = Sk - (Mk < 0 ? Mk : 0);
-	const uint64_t brk = m.B & __builtin_amdgcn_ballot_w64(x > k.max_skip);
-	const uint64_t Ap = brk ? (m.A & ((1ull << __builtin_ctzll(brk)) - 1)) : m.A;      // A lanes before the break
-	if (Ap) {
-		const int ka = 63 - __builtin_clzll(Ap);
-		max_f = __builtin_amdgcn_readlane(m.sc, ka);
-		max_j = jtop - ka;
-	}
-	n_skip = __builtin_amdgcn_readlane(x, 63);
-	return brk != 0;
-}
-
-// n_skip walk over one evaluated chunk (any n_skip on entry); returns true when the break is taken
-__device__ __forceinline__ bool fast_walk(const FastK &k, const FastMasks &m, int jtop, int &max_f, int &max_j, int &n_skip)
-{
-	const int hiA = highest_lane(m.A);
-	if ((m.B & low_mask64(hiA)) == 0) {                            // every A lane precedes every B lane (or one set is empty)
-		if (hiA >= 0) {
-			max_f = __builtin_amdgcn_readlane(m.sc, hiA);
-			max_j = jtop - hiA;
-		}
-		int x = n_skip - __builtin_popcountll(m.A);
-		x = x < 0 ? 0 : x;
-		const int cb = __builtin_popcountll(m.B);
-		n_skip = x + cb;
-		return cb > 0 && n_skip > k.max_skip;                      // break taken at a B lane (chain.c:278-279); n_skip is dead then
-	}
-	return fast_walk_general(k, m, jtop, max_f, max_j, n_skip);
-}
 
 // a further ring chunk (kb0 >= 64); returns true when the scan for anchor i is complete
 template <int RING, bool SAMEGAP>
@@ -495,57 +355,6 @@ __device__ __forceinline__ bool fast_chunk(const FastK &k, uint32_t S, int jtop,
 	if (fast_walk(k, m, jtop, max_f, max_j, n_skip)) return true;
 	// x sorted => dr grows with the lane: another chunk can only matter if the last lane is inside the window
 	return (uint32_t)__builtin_amdgcn_readlane((int)m.drm1, 63) + 1u > k.M;
-}
-
-// G consecutive ring chunks (kb0, kb0 + 64, ...) of anchor i at once.  What a chunk contributes before the serial semantics
-// -- filters, scores, marks, the prefix max inside the chunk -- does not depend on the chunks in front of it, so the G
-// evaluations are issued side by side (G ring reads and table lookups in flight, one fence for all the marks) and only the
-// walks (fast_walk: a few scalar instructions each) run one after the other, each with the running max the one before left.
-// Marks written by chunks behind the break are never read.  For long scans in the large rings, where a
-// wave has its SIMD almost to itself and a chunk at a time would leave it waiting for LDS.  Returns true when the scan for
-// anchor i is complete.
-template <int RING, bool SAMEGAP, int G>
-__device__ __forceinline__ bool fast_chunk_group(const FastK &k, uint32_t xm1, uint32_t qm1, int spm1, int i, int kb0,
-                                                 int &max_f, int &max_j, int &n_skip)
-{
-	typedef FastLds<RING> L;
-	int sc[G], tj[G], excl[G];
-	uint32_t drl[G];
-	uint64_t okm[G];
-#pragma unroll
-	for (int g = 0; g < G; ++g) {
-		const uint32_t S = (uint32_t)(i - 1 - kb0 - 64 * g) << 4;
-		const FastPairs P = fast_filters<RING, SAMEGAP>(k, (S - k.L4) & (L::RB - 1u), xm1, qm1);
-		const int dqm1 = (int)P.e.y, drm1 = (int)P.drm1;
-		int sc0 = dqm1 < drm1 ? dqm1 : drm1;
-		sc0 = sc0 < spm1 ? sc0 : spm1;
-		const uint32_t di = P.dd < k.bw ? P.dd : k.bw;
-		const int scu = sc0 + (int)P.e.z + lds_load_i16(L::LUT + 2u * di);
-		okm[g] = __builtin_amdgcn_ballot_w64(P.ok);
-		sc[g] = __builtin_amdgcn_inverse_ballot_w64(okm[g]) ? scu : INT_MIN;
-		drl[g] = P.drm1;
-		const uint32_t d4 = ((uint32_t)(i - 1) << 2) - P.e.w;
-		const uint32_t dcl = d4 < 4u * RING ? d4 : 4u * RING;
-		lds_store_b32((P.ok ? dcl : k.far4) + L::T_OFF, i);
-	}
-	wave_mem_fence();
-#pragma unroll
-	for (int g = 0; g < G; ++g) {
-		tj[g] = lds_load_b32(k.trel + ((uint32_t)(kb0 + 64 * g) << 2) + L::T_OFF);
-		excl[g] = wave_excl_max_floor0(sc[g]);
-	}
-#pragma unroll
-	for (int g = 0; g < G; ++g) {
-		FastMasks m;
-		const int e = excl[g] > max_f ? excl[g] : max_f;
-		m.sc = sc[g]; m.drm1 = drl[g];
-		m.A = __builtin_amdgcn_ballot_w64(sc[g] > e);
-		m.B = okm[g] & ~m.A & __builtin_amdgcn_ballot_w64(tj[g] == i);
-		if (fast_walk(k, m, i - 1 - kb0 - 64 * g, max_f, max_j, n_skip)) return true;
-		if ((uint32_t)__builtin_amdgcn_readlane((int)drl[g], 63) + 1u > k.M) return true;
-		if (kb0 + 64 * (g + 1) >= i) return true;                  // the unit starts here: nothing older
-	}
-	return false;
 }
 
 // A deep chunk (predecessors older than the ring) of a table-driven unit: the same arithmetic as fast_masks with
@@ -590,66 +399,6 @@ __device__ __forceinline__ bool fast_deep_chunk(const UnitCtx &c, const FastK &k
 	return __builtin_amdgcn_ballot_w64(live) != ~0ull;             // a lane outside the window (or the unit): nothing older can matter
 }
 
-// G consecutive deep chunks at once: what fast_chunk_group does for ring chunks, for predecessors that come back from HBM/L2.
-// A deep chunk costs two dependent round trips to L2 (a/f/p of the predecessors; then the marks, which the chunk's own lanes
-// may have just written); here G chunks share them -- all their loads are in flight together, one fence, all their mark
-// reads together -- and only the walks are serial.  Chunks behind the break (or behind the unit's start) are evaluated for
-// nothing; their marks are never read.  Returns true when the scan for anchor i is complete.
-template <int RING, bool SAMEGAP, int G>
-__device__ __forceinline__ bool fast_deep_group(const UnitCtx &c, const FastK &k, uint64_t xi, uint32_t qi, int spm1, int i, int kb0,
-                                                int &max_f, int &max_j, int &n_skip)
-{
-	typedef FastLds<RING> L;
-	const unsigned long long tag = c.tg_hi | (uint32_t)i;
-	ulonglong2 aj[G];
-	int fj[G], pjr[G], sc[G], excl[G];
-	unsigned long long mk[G];
-	uint64_t okm[G], livem[G];
-	wave_global_fence();                                           // f/p of earlier tiles and the marks written so far
-#pragma unroll
-	for (int g = 0; g < G; ++g) {
-		const int j = i - 1 - kb0 - 64 * g - c.lane;
-		const int64_t gj = c.base + (j >= 0 ? j : 0);
-		aj[g] = c.a[gj]; fj[g] = c.f[gj]; pjr[g] = c.p[gj];
-	}
-#pragma unroll
-	for (int g = 0; g < G; ++g) {
-		const bool inr = i - 1 - kb0 - 64 * g - c.lane >= 0;
-		const bool live = inr && xi - aj[g].x <= c.maxx;           // chain.c:252
-		const uint32_t drm1 = (uint32_t)xi - (uint32_t)aj[g].x - 1u, dqm1 = qi - (uint32_t)aj[g].y - 1u;
-		const uint32_t dd = absdiff_u32(drm1, dqm1);
-		const uint32_t dqs = SAMEGAP ? dqm1 : __builtin_elementwise_add_sat(dqm1, k.dq_off);
-		const uint32_t m2 = drm1 > dqs ? drm1 : dqs, t = dd + k.cbw;
-		const bool ok = live && (m2 > t ? m2 : t) < k.M;           // chain.c:257-260
-		int sc0 = (int)dqm1 < (int)drm1 ? (int)dqm1 : (int)drm1;
-		sc0 = sc0 < spm1 ? sc0 : spm1;
-		const uint32_t di = dd < k.bw ? dd : k.bw;
-		const int scu = sc0 + fj[g] + lds_load_i16(L::LUT + 2u * di);
-		okm[g] = __builtin_amdgcn_ballot_w64(ok);
-		livem[g] = __builtin_amdgcn_ballot_w64(live);
-		sc[g] = __builtin_amdgcn_inverse_ballot_w64(okm[g]) ? scu : INT_MIN;
-		if (ok && pjr[g] >= 0) c.tg[c.base + (pjr[g] - c.rel0)] = tag;   // chain.c:281
-	}
-	wave_global_fence();
-#pragma unroll
-	for (int g = 0; g < G; ++g) {
-		const int j = i - 1 - kb0 - 64 * g - c.lane;
-		mk[g] = c.tg[c.base + (j >= 0 ? j : 0)];
-		excl[g] = wave_excl_max_floor0(sc[g]);
-	}
-#pragma unroll
-	for (int g = 0; g < G; ++g) {
-		FastMasks m;
-		const int e = excl[g] > max_f ? excl[g] : max_f;
-		m.sc = sc[g]; m.drm1 = 0;
-		m.A = __builtin_amdgcn_ballot_w64(sc[g] > e);
-		m.B = okm[g] & ~m.A & __builtin_amdgcn_ballot_w64(mk[g] == tag);       // (okm implies j >= 0)
-		if (fast_walk(k, m, i - 1 - kb0 - 64 * g, max_f, max_j, n_skip)) return true;
-		if (livem[g] != ~0ull) return true;                        // a lane outside the window (or the unit): nothing older can matter
-	}
-	return false;
-}
-
 // chunks beyond the first for anchor i: ring chunks, then the deep path (predecessors older than the ring, from HBM/L2)
 template <int RING, bool SAMEGAP>
 __device__ __forceinline__ void fast_more_chunks(const UnitCtx &c, const FastK &k, uint32_t xhi, int i, uint32_t xm1, uint32_t qm1,
@@ -657,17 +406,10 @@ __device__ __forceinline__ void fast_more_chunks(const UnitCtx &c, const FastK &
 {
 	typedef FastLds<RING> L;
 	const int lo4 = max((i - RING) << 2, 0);           // 4 * (oldest anchor still in the ring)
-	int kb0 = 64;
-	if constexpr (RING >= CHAINDP_DEEP_RING) {
-		// long scans in the large ring: four chunks at a time while four still fit the ring
-		for (; kb0 < i && kb0 + 256 <= RING; kb0 += 256)
-			if (fast_chunk_group<RING, SAMEGAP, 4>(k, xm1, qm1, spm1, i, kb0, max_f, max_j, n_skip)) return;
-	}
-	while (kb0 < i) {
+	for (int kb0 = 64; kb0 < i; kb0 += 64) {
 		bool done;
 		if (kb0 + 64 <= RING) {
 			done = fast_chunk<RING, SAMEGAP>(k, (uint32_t)(i - 1 - kb0) << 4, i - 1 - kb0, xm1, qm1, spm1, i, kb0, max_f, max_j, n_skip);
-			kb0 += 64;
 		} else {
 			if (kb0 == RING) {
 				++c.deep_n;
@@ -678,12 +420,7 @@ __device__ __forceinline__ void fast_more_chunks(const UnitCtx &c, const FastK &
 					if (P.ok && pj4 >= 0 && pj4 < lo4) c.tg[c.base + (pj4 >> 2)] = c.tg_hi | (uint32_t)i;
 				}
 			}
-			// (the launches with the small rings run at eight waves per SIMD and have no registers for a group; a unit that keeps
-			// coming here is handed to the large-ring launch anyway)
-			constexpr int DG = RING >= CHAINDP_DEEP_RING ? CHAINDP_DEEP_GROUP : 1;
-			if constexpr (DG > 1) done = fast_deep_group<RING, SAMEGAP, DG>(c, k, (uint64_t)xhi << 32 | xm1, qm1, spm1, i, kb0, max_f, max_j, n_skip);
-			else done = fast_deep_chunk<RING, SAMEGAP>(c, k, (uint64_t)xhi << 32 | xm1, qm1, spm1, i, kb0, max_f, max_j, n_skip);
-			kb0 += 64 * DG;
+			done = fast_deep_chunk<RING, SAMEGAP>(c, k, (uint64_t)xhi << 32 | xm1, qm1, spm1, i, kb0, max_f, max_j, n_skip);
 		}
 		if (done) break;
 	}
@@ -799,58 +536,11 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 			}
 			if (ii < cnt) fast_anchor_step<RING, SAMEGAP>(c, k, an, tile0, ii, a_cur, a_alt, ap, off_next, off_last, waddr, xq);
 		}
-		// tile flush: v (chain.c:284) by pointer doubling, then f/p/v and the compaction helpers
-		{
-			int fi = 0, pi = -1, val = 0, ptr = -1;
-			if (lane < cnt) {
-				const int2 zw = lds_load_b64(waddr + 8u);
-				fi = zw.x; pi = zw.y >> 2;
-				val = fi; ptr = pi;
-			}
-			const bool ext = ptr >= 0 && ptr < tile0;               // predecessor in an earlier tile: its v is final
-			const bool ext_far = ext && tile0 - ptr > RING;          // ... and no longer in the LDS copy
-			if (__builtin_amdgcn_ballot_w64(ext_far)) wave_global_fence();
-			if (ext) {
-				const int vext = ext_far ? c.v[c.base + ptr] : lds_load_b32(L::V_OFF + ((uint32_t)(ptr & MASK) << 2));
-				val = vext > val ? vext : val;
-				ptr = -1;
-			}
-			for (int r = 0; r < 6; ++r) {
-				const int src = (ptr >= tile0 ? ptr - tile0 : lane) << 2;
-				const int pv = __builtin_amdgcn_ds_bpermute(src, val);
-				const int pp = __builtin_amdgcn_ds_bpermute(src, ptr);
-				if (ptr >= tile0) { val = pv > val ? pv : val; ptr = pp; }
-			}
-			wave_mem_fence();
-			if (lane < cnt) lds_store_b32(L::V_OFF + (waddr >> 2), val);
-			wave_mem_fence();
-			// first_child[] of an anchor that is not emitted at its own step starts at "none" here, before any child (this
-			// tile or a later one, always this wave) lowers it: no batch-wide initialisation pass
-			const bool self = val >= c.min_sc || pi >= 0;
-			if (lane < cnt && !self) c.first_child[gi] = NO_CHILD;
-			if (__builtin_amdgcn_ballot_w64(lane < cnt && !self)) wave_global_fence();
-			if (lane < cnt) {
-				c.f[gi] = fi;
-				c.p[gi] = pi < 0 ? -1 : pi + c.rel0;
-				c.v[gi] = val;
-				// Compaction (chain.c:286-317) needs, for every anchor that is not emitted at its own step, its
-				// first child; while f/p/v of the tile are at hand, record "emitted at own step" and feed that min.
-				int maybe_first = 0;
-				if (pi >= 0) {
-					int vq, pq;
-					if (tile0 + cnt - 1 - pi < RING) {
-						vq = lds_load_b32(L::V_OFF + ((uint32_t)(pi & MASK) << 2));
-						pq = lds_load_b32(((uint32_t)(pi & MASK) << 4) + 12u);
-					} else { vq = c.v[c.base + pi]; pq = c.p[c.base + pi]; }
-					if (!(vq >= c.min_sc || pq >= 0)) { atomicMin(&c.first_child[c.base + pi], c.rel0 + tile0 + lane); maybe_first = 4; }
-				}
-				c.flags[gi] = (uint8_t)((self ? 2 : 0) | maybe_first | (val >= c.min_sc ? 8 : 0) | (fi < val ? 16 : 0));   // bits 3,4: the record's flag bits (chain.c:313-314)
-			}
-		}
+		fast_flush_tile<RING>(c, tile0, cnt, waddr, gi);      // v (chain.c:284), f/p/v, the compaction helpers
 		if (cnt < 64) break;
-		// A unit whose scans keep reaching past the ring (dense repeats: the window holds hundreds of predecessors and
-		// few of them are marked) spends its time in round trips to L2.  It is handed to the launch with the large ring,
-		// which redoes it from scratch; what this wave has stored so far is what that launch stores again.
+		// A unit whose scans keep reaching past the ring (dense repeats: the window holds hundreds of predecessors and few of
+		// them are marked) spends its time in round trips to L2.  It is handed to k_chain_dense, which redoes it from scratch;
+		// what this wave has stored so far is what that kernel stores again.
 		if (c.deep_list && c.deep_n >= CHAINDP_DEEP_HANDOVER && tile0 + 64 < room) {
 			if (lane == 0) { Unit un; un.start = c.base; un.read = c.read; un.len = (int32_t)room; c.deep_list[atomicAdd(c.deep_cnt, 1u)] = un; }
 			return;
@@ -859,7 +549,7 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 }
 
 template <int RING>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RING >= CHAINDP_DEEP_RING ? 2 : 8, 8))) void k_chain_units(Params par, const int64_t *__restrict__ off,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_chain_units(Params par, const int64_t *__restrict__ off,
                                                     const ulonglong2 *__restrict__ a, const int32_t *__restrict__ n_segs_pr,
                                                     const unsigned long long *__restrict__ sumq,
                                                     const uint16_t *__restrict__ lut, int lut_stride,
@@ -883,7 +573,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RING >= CHAI
 	uint16_t *s_lut = (uint16_t*)(c.s_yhi + RING + 4);
 	c.s_lut = s_lut;
 	c.lane = threadIdx.x;
-	c.deep_list = RING >= CHAINDP_DEEP_RING ? nullptr : deep_list; c.deep_cnt = deep_cnt;
+	// k_chain_dense keeps 32-bit differences over a ring of CHAINDP_DENSE_RING anchors: exact under the same condition as x32_ok below
+	c.deep_list = ((uint64_t)(int64_t)par.max_dist_x + 1) * (uint64_t)(CHAINDP_DENSE_RING + 1) < (1ull << 32) ? deep_list : nullptr;
+	c.deep_cnt = deep_cnt;
 	c.maxx = (uint64_t)(int64_t)par.max_dist_x;
 	c.mdx = par.max_dist_x; c.mdy = par.max_dist_y; c.bw = par.bw; c.max_skip = par.max_skip; c.is_cdna = par.is_cdna;
 	c.mdq = par.max_dist_x < par.max_dist_y ? par.max_dist_x : par.max_dist_y;   // dq > max_dist_y || dq > max_dist_x (same segment)
@@ -945,42 +637,21 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
 	if (blocks > cap) blocks = cap;
 	const ulonglong2 *aa = (const ulonglong2*)d_a;
 	const size_t lds = chain_lds_bytes(ring, d_lut ? lut_stride : 0);
-	const void *fn = ring == 128 ? (const void*)k_chain_units<128> : ring == 512 ? (const void*)k_chain_units<512> :
-	                 ring == CHAINDP_DEEP_RING ? (const void*)k_chain_units<CHAINDP_DEEP_RING> : (const void*)k_chain_units<256>;
 	{
 		// the fast variant addresses LDS by raw byte offsets from 0: the kernel must have no static LDS in front of
 		// its dynamic segment
 		hipFuncAttributes fa;
+		const void *fn = ring == 128 ? (const void*)k_chain_units<128> : ring == 512 ? (const void*)k_chain_units<512> : (const void*)k_chain_units<256>;
 		const hipError_t e = hipFuncGetAttributes(&fa, fn);
 		if (e != hipSuccess) return e;
 		if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
 	}
-	if (lds > 64 * 1024) {
-		const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		if (e != hipSuccess) return e;
-	}
-#define CHAINDP_LAUNCH_UNITS(R) hipLaunchKernelGGL(k_chain_units<R>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, \
-		d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt)
 	switch (ring) {
-	case 128: CHAINDP_LAUNCH_UNITS(128); break;
-	case 512: CHAINDP_LAUNCH_UNITS(512); break;
-	case CHAINDP_DEEP_RING: CHAINDP_LAUNCH_UNITS(CHAINDP_DEEP_RING); break;
-	default:  CHAINDP_LAUNCH_UNITS(256); break;
+	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt); break;
+	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt); break;
+	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt); break;
 	}
-#undef CHAINDP_LAUNCH_UNITS
 	return hipGetLastError();
-}
-
-// the units the launches above handed over because their scans keep reaching past the ring: the same kernel with a ring of
-// 1024 anchors (34 KB of LDS per wave, so a wave per SIMD), one wave per unit, as many waves as the chip holds at that size
-hipError_t launch_chain_deep(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
-                             const int32_t *d_n_segs, const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
-                             const Unit *d_deep, const unsigned long long *d_deep_cnt,
-                             int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags)
-{
-	if (max_units > 2048) max_units = 2048;
-	return launch_chain(st, CHAINDP_DEEP_RING, par, max_units, d_off, d_a, d_n_segs, d_sumq, d_lut, lut_stride, d_deep, d_deep_cnt,
-	                    d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, nullptr, nullptr, nullptr, nullptr);
 }
 
 } // namespace chaindp

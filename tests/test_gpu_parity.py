@@ -17,7 +17,7 @@ def dev():
         yield d
 
 
-@pytest.mark.parametrize("ring,general", [(128, 0), (256, 0), (512, 0), (128, 1), (256, 1), (128, 2), (256, 2), (512, 2), (1024, 2)])
+@pytest.mark.parametrize("ring,general", [(128, 0), (256, 0), (512, 0), (128, 1), (256, 1), (128, 2), (256, 2), (512, 2)])
 @pytest.mark.parametrize("name", golden_names())
 def test_golden_fixture_bit_exact(dev, name, ring, general):
     """Every fixture through the three ways the DP can run -- 0: two units per wave (k_chain_twin) with k_chain_units for what it
@@ -115,15 +115,16 @@ def test_large_bw_takes_the_general_path(dev):
     dict(max_skip=-1, max_dist_y=700),
 ])
 @pytest.mark.parametrize("gen,n_reads", [("dense", 2), ("ties", 40)])
-@pytest.mark.parametrize("ring,handover", [(128, False), (512, False), (128, True), (1024, False)])
-def test_fast_variant_parameter_corners(dev, par_over, gen, n_reads, ring, handover):
+@pytest.mark.parametrize("ring,handover,bitcap", [(128, False, 65536), (512, False, 65536), (128, True, 65536), (128, True, 1024), (256, True, 512)])
+def test_fast_variant_parameter_corners(dev, par_over, gen, n_reads, ring, handover, bitcap):
     """The table-driven variant folds the window, gap and bandwidth tests of chain.c:252-260 into one unsigned compare and keeps
     marks by distance; 'dense' walks the whole window (ring chunks, far marks, the deep path), 'ties' breaks early.  Without the
-    handover a small ring serves the long scans of the dense units from HBM/L2 to the end; with it they are redone by the
-    launch with the 1024-anchor ring."""
+    handover k_chain_units serves the long scans of the dense units from HBM/L2 to the end; with it they are redone by
+    k_chain_dense (marks as bits by distance in LDS; a small bitmap sends the marks behind it through the global array)."""
     dev.set_ring(ring)
     dev.set_variant(False)
     dev.set_deep_handover(handover)
+    dev.set_dense_bitcap(bitcap)
     try:
         par = P.preset("ava-ont", **par_over)
         off, a = ag.generate(gen, n_reads=n_reads, seed=77, **(dict(read_len=2500, n_hits=10) if gen == "dense" else {}))
@@ -137,27 +138,49 @@ def test_fast_variant_parameter_corners(dev, par_over, gen, n_reads, ring, hando
             assert seeds[int(soff[r]):int(soff[r + 1])].tobytes() == exp.tobytes(), (par_over, gen, r)
     finally:
         dev.set_deep_handover(True)
+        dev.set_dense_bitcap(65536)
         dev.set_ring(128)
 
 
-def test_dense_units_are_redone_with_the_large_ring(dev):
-    """Default settings: units whose scans keep reaching past the LDS ring (dense repeats) are handed by k_chain_units to its launch
-    with the 1024-anchor ring, which redoes them from scratch -- same f/p/v and new_seed[] as the oracle."""
+@pytest.mark.parametrize("bitcap", [65536, 2048, 512])
+def test_dense_units_are_redone_by_the_dense_kernel(dev, bitcap):
+    """Default settings: units whose scans keep reaching past the LDS ring (dense repeats) are handed by k_chain_units to
+    k_chain_dense, which redoes them from scratch -- same f/p/v and new_seed[] as the oracle.  With a small mark bitmap the
+    scans that cross a whole unit also take the path behind it (marks in the global array)."""
     dev.set_ring(128)
+    dev.set_dense_bitcap(bitcap)
     par = P.preset("ava-ont")
     off, a = ag.generate("dense", n_reads=3, seed=5, read_len=3000, n_hits=12)
     of, op, ov, _ = ol.oracle_batch(par, off, a, threads=8)
-    for variant in (0, 2):
-        dev.set_variant(variant)
-        f, p, v = dev.chain_batch(par, off, a)
-        assert dev.deep_units() > 0, variant
-        assert np.array_equal(f, of) and np.array_equal(p, op) and np.array_equal(v, ov), variant
-        soff, seeds = dev.compact(par)
-        for r in range(len(off) - 1):
-            lo, hi = int(off[r]), int(off[r + 1])
-            exp = ol.oracle_compact(par, np.ascontiguousarray(a[lo:hi]), of[lo:hi].copy(), op[lo:hi].copy(), ov[lo:hi].copy())
-            assert seeds[int(soff[r]):int(soff[r + 1])].tobytes() == exp.tobytes(), (variant, r)
-    dev.set_variant(0)
+    try:
+        for variant in (0, 2):
+            dev.set_variant(variant)
+            f, p, v = dev.chain_batch(par, off, a)
+            assert dev.deep_units() > 0, variant
+            assert np.array_equal(f, of) and np.array_equal(p, op) and np.array_equal(v, ov), variant
+            soff, seeds = dev.compact(par)
+            for r in range(len(off) - 1):
+                lo, hi = int(off[r]), int(off[r + 1])
+                exp = ol.oracle_compact(par, np.ascontiguousarray(a[lo:hi]), of[lo:hi].copy(), op[lo:hi].copy(), ov[lo:hi].copy())
+                assert seeds[int(soff[r]):int(soff[r + 1])].tobytes() == exp.tobytes(), (variant, r)
+    finally:
+        dev.set_variant(0)
+        dev.set_dense_bitcap(65536)
+
+
+def test_dense_unit_longer_than_the_mark_bitmap(dev):
+    """A unit of more than 65536 anchors whose scans cross it end to end: marks behind the bitmap's 64 K distances go through the
+    global array at the kernel's real size."""
+    dev.set_ring(128)
+    par = P.preset("ava-ont")
+    off, a = ag.generate("dense", n_reads=1, seed=9, read_len=14000, n_hits=28)        # units of 62 k and 98 k anchors
+    x = a[:, 0]
+    cuts = np.flatnonzero((x[1:] >> np.uint64(32)) != (x[:-1] >> np.uint64(32))) + 1
+    assert max(np.diff(np.concatenate(([0], cuts, [len(x)])))) > 65536 + 4096
+    of, op, ov, _ = ol.oracle_batch(par, off, a, threads=8)
+    f, p, v = dev.chain_batch(par, off, a)
+    assert dev.deep_units() > 0
+    assert np.array_equal(f, of) and np.array_equal(p, op) and np.array_equal(v, ov)
 
 
 def test_reference_position_crossing_2_to_32(dev):

@@ -14,7 +14,7 @@ for n_reads in [int(x) for x in sys.argv[1:]] or [100]:
     total = int(off[-1])
     with chaindp.Device(0, max_anchors=total + 1, max_reads=n_reads + 1) as dev:
         dev.upload(off, a)
-        cases = (("ring128, no handover", 128, False), ("ring128 + handover", 128, True), ("ring1024 direct", 1024, False))
+        cases = (("k_chain_units alone", 128, False), ("handover to k_chain_dense", 128, True))
         if os.environ.get("CHAINDP_LIB"):
             cases = cases[1:2]
         for label, ring, handover in cases:
