@@ -330,13 +330,6 @@ class Device:
         self._lib.chaindp_debug_set_deep_handover.argtypes = [C.c_void_p, C.c_int]
         self._check(self._lib.chaindp_debug_set_deep_handover(self._ctx, int(bool(on))))
 
-    def set_dense_bitcap(self, bitcap=65536):
-        """Test hook: distances k_chain_dense's LDS mark bitmap covers (multiple of 512, at most 65536); marks on older
-        predecessors go through the global mark array, which a small value makes reachable for units of a few thousand anchors."""
-        self._lib.chaindp_debug_set_dense_bitcap.restype = C.c_int
-        self._lib.chaindp_debug_set_dense_bitcap.argtypes = [C.c_void_p, C.c_int]
-        self._check(self._lib.chaindp_debug_set_dense_bitcap(self._ctx, int(bitcap)))
-
     def stats(self):
         st = (C.c_int64 * 4)()
         self._check(self._lib.chaindp_get_stats(self._ctx, st))

@@ -39,7 +39,6 @@ struct chaindp_ctx {
 	Unit *d_left = nullptr;               // units the two-per-wave kernel hands over to k_chain_units
 	unsigned long long *d_left_cnt = nullptr;   // [0] handed-over count | the twin kernel's queue << 32; [1] count of d_deep
 	Unit *d_deep = nullptr;               // units k_chain_units hands over to its k_chain_dense (scans that keep reaching past the ring)
-	int dense_bitcap = CHAINDP_DENSE_BITCAP; // distances k_chain_dense's mark bitmap covers (test hook: smaller)
 	bool deep_handover = true;            // CHAINDP_NO_DEEP_HANDOVER (diagnostic / A-B): every unit stays in the launch that took it
 	int variant = 0;                      // 0: k_chain_twin + k_chain_units for the rest; 1: k_chain_units, general variant; 2: k_chain_units only
 	unsigned long long *d_counters = nullptr;
@@ -278,9 +277,8 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		                                   nullptr, nullptr, deep, deep_cnt));
 	// units whose scans kept reaching past the ring (dense repeats): redone by k_chain_dense
 	if (deep && lut)
-		HIP_TRY(ctx, chaindp::launch_chain_dense(st, q, total / 128 + 1, d_off, d_a, ctx->d_sumq, lut, lut_stride, ctx->d_deep,
-		                                         ctx->d_left_cnt + 1, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
-		                                         ctx->dense_bitcap));
+		HIP_TRY(ctx, chaindp::launch_chain_dense(st, q, total / 128 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,
+		                                         d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags));
 	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[2], st)); ctx->pending.push_back(es); }
 	ctx->stats[2] = total; ctx->stats[3] = n_reads;
 	return CHAINDP_OK;
@@ -591,15 +589,6 @@ extern "C" int chaindp_debug_set_deep_handover(chaindp_ctx_t *ctx, int on)
 {
 	if (!ctx) return CHAINDP_ERR_ARG;
 	ctx->deep_handover = on != 0;
-	return CHAINDP_OK;
-}
-
-// test hook (not in the public header): distances the mark bitmap of k_chain_dense covers (a multiple of 512); marks on
-// older predecessors go through the global mark array, which a small value makes reachable for units of a few thousand anchors
-extern "C" int chaindp_debug_set_dense_bitcap(chaindp_ctx_t *ctx, int bitcap)
-{
-	if (!ctx || bitcap < 512 || bitcap > CHAINDP_DENSE_BITCAP || bitcap % 512) return CHAINDP_ERR_ARG;
-	ctx->dense_bitcap = bitcap;
 	return CHAINDP_OK;
 }
 

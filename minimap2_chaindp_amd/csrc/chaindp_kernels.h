@@ -52,16 +52,14 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
                         const Unit *d_units_all = nullptr, const unsigned long long *d_counters_all = nullptr,
                         Unit *d_deep = nullptr, unsigned int *d_deep_cnt = nullptr);
 // Units whose scans keep reaching past the ring (dense repeats) are appended to d_deep / *d_deep_cnt by the launch above (when
-// given) and redone by k_chain_dense (chaindp_dense.hip): one wave per unit, marks as one bit per distance in LDS, several
-// chunks of predecessors evaluated per trip to LDS / L2.  The low 32 bits of *d_deep_cnt are the count; bitcap = distances the
-// LDS mark bitmap covers (a multiple of 512, at most CHAINDP_DENSE_BITCAP; smaller values only to test the path behind it).
+// given) and redone by k_chain_dense (chaindp_dense.hip): a workgroup of four waves per unit, marks as one bit per distance in
+// LDS.  The low 32 bits of *d_deep_cnt are the count.  Only units of at most CHAINDP_DENSE_BITCAP anchors are handed over (the
+// bitmap covers that many distances), and only while 32-bit differences are exact over a ring of CHAINDP_DENSE_RING anchors.
 #define CHAINDP_DENSE_BITCAP 65536
-#define CHAINDP_DENSE_RING 512        // its LDS ring; a unit is only handed over if 32-bit differences are exact over that span
+#define CHAINDP_DENSE_RING 512
 hipError_t launch_chain_dense(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
-                              const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride,
-                              const Unit *d_deep, const unsigned long long *d_deep_cnt,
-                              int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags,
-                              int bitcap);
+                              const uint16_t *d_lut, int lut_stride, const Unit *d_deep, const unsigned long long *d_deep_cnt,
+                              int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags);
 
 // Two units per wave, 32 lanes each (chaindp_twin.hip): takes the ordinary units, appends the others (general-variant reads,
 // scans that reach beyond 64 predecessors) to d_left / *d_left_cnt (low 32 bits = count), which launch_chain then runs.

@@ -541,7 +541,7 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 		// A unit whose scans keep reaching past the ring (dense repeats: the window holds hundreds of predecessors and few of
 		// them are marked) spends its time in round trips to L2.  It is handed to k_chain_dense, which redoes it from scratch;
 		// what this wave has stored so far is what that kernel stores again.
-		if (c.deep_list && c.deep_n >= CHAINDP_DEEP_HANDOVER && tile0 + 64 < room) {
+		if (c.deep_list && c.deep_n >= CHAINDP_DEEP_HANDOVER && tile0 + 64 < room && room <= CHAINDP_DENSE_BITCAP) {
 			if (lane == 0) { Unit un; un.start = c.base; un.read = c.read; un.len = (int32_t)room; c.deep_list[atomicAdd(c.deep_cnt, 1u)] = un; }
 			return;
 		}
