@@ -270,11 +270,11 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		const int64_t left_grid = total / 2 < 32768 ? total / 2 : 32768;
 		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, left_grid, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_left,
 		                                   ctx->d_left_cnt, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
-		                                   ctx->d_units, ctx->d_counters, deep, deep_cnt));
+		                                   ctx->d_units, ctx->d_counters, deep, deep_cnt, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS));
 	} else
 		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, total / 2, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_units,
 		                                   ctx->d_counters, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
-		                                   nullptr, nullptr, deep, deep_cnt));
+		                                   nullptr, nullptr, deep, deep_cnt, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS));
 	// units whose scans kept reaching past the ring (dense repeats): redone by k_chain_dense
 	if (deep && lut)
 		HIP_TRY(ctx, chaindp::launch_chain_dense(st, q, total / 128 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,

@@ -32,25 +32,32 @@
 namespace chaindp {
 
 #define DN_RING CHAINDP_DENSE_RING
-#define DN_WAVES 4                      // waves per unit
-#define DN_CPW 2                        // chunks a wave evaluates per round
-#define DN_ROUND (DN_WAVES * DN_CPW)    // chunks per round
+#ifndef DN_WAVES
+#define DN_WAVES 8                      // waves per unit
+#endif
+#define DN_ROUND 8                      // chunks per round
+#define DN_CPW (DN_ROUND / DN_WAVES)    // chunks a wave evaluates per round
+static_assert(DN_CPW * DN_WAVES == DN_ROUND && DN_WAVES >= 2, "the waves must tile the round");
 static_assert(64 * DN_ROUND == DN_RING, "the first round is the ring");
 typedef FastLds<DN_RING> DnL;
 // LDS (dynamic segment, raw byte offsets from 0): ring entries [0, 8 K) and v[] [10 K, 12 K) as FastLds<512> lays them out (the
 // tile flush is shared with k_chain_units); the mark bitmap; a word per thread where a lane without a mark ORs its zero (LDS
-// atomics of one instruction on ONE address take a turn each); what the round's chunks leave for wave 0: score and exclusive
-// prefix max per lane, lane mask of passing predecessors and an end flag per chunk; wave 0's verdict; the read's table of
-// 1 - cost (int16)
+// atomics of one instruction on ONE address take a turn each); what the waves tell each other about a round's chunks, twice (a
+// round uses the half of its parity, so that a wave may start the next round while another still reads this one's): the
+// chunk's scores per lane, its maximum, its summary; the read's table of 1 - cost (int16)
 #define DN_BM 12288u
-#define DN_SINK (DN_BM + CHAINDP_DENSE_BITCAP / 8u)
+#define DN_BM_BYTES (CHAINDP_DENSE_BITCAP / 8u)
+#define DN_SINK (DN_BM + DN_BM_BYTES)
 #define DN_SC (DN_SINK + 4u * 64u * DN_WAVES)
-#define DN_EX (DN_SC + 256u * DN_ROUND)
-#define DN_OKM (DN_EX + 256u * DN_ROUND)
-#define DN_END (DN_OKM + 8u * DN_ROUND)
-#define DN_RES (DN_END + 4u * DN_ROUND)
-#define DN_LUT ((DN_RES + 4u + 15u) & ~15u)
+#define DN_SC_HALF (256u * DN_ROUND)
+#define DN_M (DN_SC + 2u * DN_SC_HALF)
+#define DN_M_HALF (4u * DN_ROUND)
+#define DN_SUM (DN_M + 2u * DN_M_HALF)
+#define DN_SUM_CHUNK 48u                // a, b, thr, flags | sc and lane of the chunk's last new maximum, pad | A, B lane masks
+#define DN_SUM_HALF (DN_SUM_CHUNK * DN_ROUND)
+#define DN_LUT ((DN_SUM + 2u * DN_SUM_HALF + 15u) & ~15u)
 static_assert(DnL::V_OFF + 4u * DN_RING <= DN_BM, "v[] runs into the bitmap");
+#define DN_NEG (-(1 << 28))             // "minus infinity" that survives a few additions
 
 struct DenseArgs {
 	Params par;
@@ -72,31 +79,31 @@ __device__ __forceinline__ void dn_or_b32(uint32_t a, uint32_t v)
 
 // chain.c:281 for one lane: the predecessor's predecessor p (4 * its unit-relative index, negative: none) is marked: bit
 // i - 1 - p of the bitmap (i1x4 = 4 (i - 1)).  A lane without a mark ORs a zero into its own sink word: nothing is masked off.
-__device__ __forceinline__ void dn_mark(uint32_t sink, uint32_t i1x4, bool ok, uint32_t p4)
+__device__ __forceinline__ void dn_mark(uint32_t bm, uint32_t sink, uint32_t i1x4, bool ok, uint32_t p4)
 {
 	const uint32_t d4 = i1x4 - p4;
 	const bool has = ok && (int)p4 >= 0;
-	dn_or_b32(has ? DN_BM + ((d4 >> 7) << 2) : sink, has ? 1u << ((d4 >> 2) & 31u) : 0u);
+	dn_or_b32(has ? bm + ((d4 >> 7) << 2) : sink, has ? 1u << ((d4 >> 2) & 31u) : 0u);
 }
 
-// what a chunk leaves for wave 0 (slot c of the round)
-__device__ __forceinline__ void dn_publish(uint32_t lane4, int c, int sc, uint64_t okm, bool ends)
+// the 64 mark bits of the chunk that starts kb predecessors back, as a lane mask (every lane reads the same word)
+__device__ __forceinline__ uint64_t dn_marked(uint32_t bm, uint32_t kb)
 {
-	const int excl = wave_excl_max_floor0(sc);
-	lds_store_b32(DN_SC + 256u * (uint32_t)c + lane4, sc);
-	lds_store_b32(DN_EX + 256u * (uint32_t)c + lane4, excl);
-	if (lane4 == 0) {
-		lds_store_b32(DN_OKM + 8u * (uint32_t)c, (int)(uint32_t)okm);
-		lds_store_b32(DN_OKM + 8u * (uint32_t)c + 4u, (int)(uint32_t)(okm >> 32));
-		lds_store_b32(DN_END + 4u * (uint32_t)c, ends ? 1 : 0);
-	}
+	const int2 w = lds_load_b64(bm + (kb >> 3));
+	return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(w.y) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane(w.x);
 }
 
-// One ring chunk of anchor i (slot c of the first round: predecessors j = i - 1 - 64 c - lane): filters, score, mark.
+// what a chunk contributes before the serial semantics are applied (lane <-> predecessor j = jtop - lane)
+struct DenseChunk {
+	int sc;                             // score incl. f[j] (chain.c:262-273); INT_MIN where the filters of chain.c:252-261 fail
+	uint64_t okm;                       // lanes that pass them
+	bool ends;                          // nothing older than this chunk can matter (window or unit exhausted)
+};
+
+// The ring chunk that starts kb predecessors back (first round): filters, score, mark.
 template <bool SAMEGAP>
-__device__ __forceinline__ void dn_ring_chunk(const FastK &k, uint32_t sink, uint32_t xm1, uint32_t qm1, int spm1, int i, int c)
+__device__ __forceinline__ DenseChunk dn_ring_chunk(const FastK &k, uint32_t bm, uint32_t sink, uint32_t xm1, uint32_t qm1, int spm1, int i, int kb)
 {
-	const int kb = 64 * c;
 	const uint32_t S = (uint32_t)(i - 1 - kb) << 4;
 	const FastPairs P = fast_filters<DN_RING, SAMEGAP>(k, (S - k.L4) & (DnL::RB - 1u), xm1, qm1);
 	const int dqm1 = (int)P.e.y, drm1 = (int)P.drm1;
@@ -104,87 +111,88 @@ __device__ __forceinline__ void dn_ring_chunk(const FastK &k, uint32_t sink, uin
 	sc0 = sc0 < spm1 ? sc0 : spm1;                                                      // chain.c:262-263, minus one
 	const uint32_t di = P.dd < k.bw ? P.dd : k.bw;
 	const int scu = sc0 + (int)P.e.z + lds_load_i16(DN_LUT + 2u * di);                   // chain.c:272-273 via the table
-	const uint64_t okm = __builtin_amdgcn_ballot_w64(P.ok);
-	const int sc = __builtin_amdgcn_inverse_ballot_w64(okm) ? scu : INT_MIN;
-	dn_mark(sink, (uint32_t)(i - 1) << 2, P.ok, P.e.w);
+	DenseChunk r;
+	r.okm = __builtin_amdgcn_ballot_w64(P.ok);
+	r.sc = __builtin_amdgcn_inverse_ballot_w64(r.okm) ? scu : INT_MIN;
+	dn_mark(bm, sink, (uint32_t)(i - 1) << 2, P.ok, P.e.w);
 	// the scan ends behind this chunk if its last lane is outside the window (x is sorted) or the unit starts here
-	const bool ends = (uint32_t)__builtin_amdgcn_readlane((int)P.drm1, 63) + 1u > k.M || kb + 64 >= i;
-	dn_publish(k.L4 >> 2, c, sc, okm, ends);
+	r.ends = (uint32_t)__builtin_amdgcn_readlane((int)P.drm1, 63) + 1u > k.M || kb + 64 >= i;
+	return r;
 }
 
-// Two deep chunks of anchor i (slots c0, c0 + 1 of a later round: predecessors j = i - 1 - kb - lane older than the ring; a, f, p
-// come back from HBM/L2, all six loads in flight together).  Only the window test is done in 64 bits (x_i - x_j of a
-// predecessor this old may exceed 32 bits; for a lane inside the window it does not, and every other difference is bounded by
-// the window).
+// The deep chunk that starts kb predecessors back (a later round: older than the ring; a, f, p come back from HBM/L2).  Only the
+// window test is done in 64 bits (x_i - x_j of a predecessor this old may exceed 32 bits; for a lane inside the window it does
+// not, and every other difference is bounded by the window).
 template <bool SAMEGAP>
-__device__ __forceinline__ void dn_deep_chunks(const UnitCtx &c, const FastK &k, uint32_t sink, uint64_t xi, uint32_t qi, int spm1, int i,
-                                               int kbr, int c0)
+__device__ __forceinline__ DenseChunk dn_deep_chunk(const UnitCtx &c, const FastK &k, uint32_t bm, uint32_t sink, uint64_t xi, uint32_t qi, int spm1, int i, int kb)
 {
-	ulonglong2 aj[DN_CPW];
-	int fj[DN_CPW], pjr[DN_CPW];
-#pragma unroll
-	for (int g = 0; g < DN_CPW; ++g) {
-		const int j = i - 1 - kbr - 64 * (c0 + g) - c.lane;
-		const int64_t gj = c.base + (j >= 0 ? j : 0);
-		aj[g] = c.a[gj]; fj[g] = c.f[gj]; pjr[g] = c.p[gj];                             // (p is stored read-relative)
-	}
-#pragma unroll
-	for (int g = 0; g < DN_CPW; ++g) {
-		const bool inr = i - 1 - kbr - 64 * (c0 + g) - c.lane >= 0;
-		const bool live = inr && xi - aj[g].x <= c.maxx;                                // chain.c:252
-		const uint32_t drm1 = (uint32_t)xi - (uint32_t)aj[g].x - 1u, dqm1 = qi - (uint32_t)aj[g].y - 1u;
-		const uint32_t dd = absdiff_u32(drm1, dqm1);
-		const uint32_t dqs = SAMEGAP ? dqm1 : __builtin_elementwise_add_sat(dqm1, k.dq_off);
-		const uint32_t m2 = drm1 > dqs ? drm1 : dqs, t = dd + k.cbw;
-		const bool ok = live && (m2 > t ? m2 : t) < k.M;                                // chain.c:257-260 (one compare, as fast_filters)
-		int sc0 = (int)dqm1 < (int)drm1 ? (int)dqm1 : (int)drm1;
-		sc0 = sc0 < spm1 ? sc0 : spm1;
-		const uint32_t di = dd < k.bw ? dd : k.bw;
-		const int scu = sc0 + fj[g] + lds_load_i16(DN_LUT + 2u * di);
-		const uint64_t okm = __builtin_amdgcn_ballot_w64(ok);
-		const int sc = __builtin_amdgcn_inverse_ballot_w64(okm) ? scu : INT_MIN;
-		dn_mark(sink, (uint32_t)(i - 1) << 2, ok, pjr[g] >= 0 ? (uint32_t)(pjr[g] - c.rel0) << 2 : 0xfffffffcu);
-		// a lane outside the window (or the unit): nothing older can matter
-		dn_publish(k.L4 >> 2, c0 + g, sc, okm, __builtin_amdgcn_ballot_w64(live) != ~0ull);
-	}
+	const int j = i - 1 - kb - c.lane;
+	const bool inr = j >= 0;
+	const int64_t gj = c.base + (inr ? j : 0);
+	const ulonglong2 aj = c.a[gj];
+	const int fj = c.f[gj];
+	const int pjr = c.p[gj];                                                            // stored read-relative
+	const bool live = inr && xi - aj.x <= c.maxx;                                       // chain.c:252
+	const uint32_t drm1 = (uint32_t)xi - (uint32_t)aj.x - 1u, dqm1 = qi - (uint32_t)aj.y - 1u;
+	const uint32_t dd = absdiff_u32(drm1, dqm1);
+	const uint32_t dqs = SAMEGAP ? dqm1 : __builtin_elementwise_add_sat(dqm1, k.dq_off);
+	const uint32_t m2 = drm1 > dqs ? drm1 : dqs, t = dd + k.cbw;
+	const bool ok = live && (m2 > t ? m2 : t) < k.M;                                    // chain.c:257-260 (one compare, as fast_filters)
+	int sc0 = (int)dqm1 < (int)drm1 ? (int)dqm1 : (int)drm1;
+	sc0 = sc0 < spm1 ? sc0 : spm1;
+	const uint32_t di = dd < k.bw ? dd : k.bw;
+	const int scu = sc0 + fj + lds_load_i16(DN_LUT + 2u * di);
+	DenseChunk r;
+	r.okm = __builtin_amdgcn_ballot_w64(ok);
+	r.sc = __builtin_amdgcn_inverse_ballot_w64(r.okm) ? scu : INT_MIN;
+	dn_mark(bm, sink, (uint32_t)(i - 1) << 2, ok, pjr >= 0 ? (uint32_t)(pjr - c.rel0) << 2 : 0xfffffffcu);
+	r.ends = __builtin_amdgcn_ballot_w64(live) != ~0ull;            // a lane outside the window (or the unit): nothing older can matter
+	return r;
 }
 
-// Wave 0, after the round's chunks are in LDS: the serial semantics of chain.c:274-279 chunk by chunk.  Returns true when the
-// scan for anchor i is complete (break taken, window or unit exhausted).
-__device__ __forceinline__ bool dn_walk_round(const FastK &k, int i, int kbr, int &max_f, int &max_j, int &n_skip)
+// inclusive prefix over the first eight lanes (one per chunk of the round) with row_shr steps
+__device__ __forceinline__ int dn_scan8_max(int v)
 {
-	const uint32_t lane4 = k.L4 >> 2;
-	// lane c < 8 fetches chunk c's mask of passing predecessors, its 64 mark bits and its end flag
-	int2 okw = make_int2(0, 0), mkw = make_int2(0, 0);
-	int endw = 0;
-	if (lane4 < 4u * DN_ROUND) {
-		okw = lds_load_b64(DN_OKM + 2u * lane4);
-		mkw = lds_load_b64(DN_BM + ((uint32_t)kbr >> 3) + 2u * lane4);
-		endw = lds_load_b32(DN_END + lane4);
+	v = max(v, dpp_or_old<DPP_ROW_SHR(1), 0xf>(INT_MIN, v));
+	v = max(v, dpp_or_old<DPP_ROW_SHR(2), 0xf>(INT_MIN, v));
+	v = max(v, dpp_or_old<DPP_ROW_SHR(4), 0xf>(INT_MIN, v));
+	return v;
+}
+
+// The n_skip walk of chain.c:276-279 over one chunk, as a function of the n_skip it starts from: lanes of A (new running
+// maximum) take x -> max(x - 1, 0), lanes of B (marked, not better) x -> x + 1 and break when x > max_skip.  With S_k = #B - #A
+// over the lanes up to k, the walk from x is S_k + max(x, -min_{m<=k} S_m): the chunk maps x to max(x + a, b), and it breaks
+// iff x >= thr.  When every A lane precedes every B lane -- nearly always -- that is two popcounts.
+struct DenseWalk { int a, b, thr; bool inter; };
+
+__device__ __forceinline__ DenseWalk dn_chunk_walk(const FastK &k, uint64_t A, uint64_t B, int hiA)
+{
+	DenseWalk r;
+	const int cA = __builtin_popcountll(A), cB = __builtin_popcountll(B);
+	r.inter = (B & low_mask64(hiA)) != 0;                           // a B lane below an A lane (hiA = -64 for no A lane: empty mask)
+	if (__builtin_expect(!r.inter, 1)) {
+		r.a = cB - cA; r.b = cB;
+		r.thr = cB == 0 ? INT_MAX : (cB > k.max_skip ? 0 : k.max_skip + 1 - cB + cA);
+		return r;
 	}
-#pragma unroll 1
-	for (int c = 0; c < DN_ROUND; ++c) {
-		FastMasks m;
-		m.sc = lds_load_b32(DN_SC + 256u * (uint32_t)c + lane4);
-		const int ex = lds_load_b32(DN_EX + 256u * (uint32_t)c + lane4);
-		const uint64_t okm = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(okw.y, c) << 32 | (uint32_t)__builtin_amdgcn_readlane(okw.x, c);
-		const uint64_t mk = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(mkw.y, c) << 32 | (uint32_t)__builtin_amdgcn_readlane(mkw.x, c);
-		const int e = ex > max_f ? ex : max_f;
-		m.drm1 = 0;
-		m.A = __builtin_amdgcn_ballot_w64(m.sc > e);                                    // new running max (chain.c:274); masked lanes hold INT_MIN
-		m.B = okm & ~m.A & mk;                                                          // marked and not better (chain.c:277)
-		if (fast_walk(k, m, i - 1 - kbr - 64 * c, max_f, max_j, n_skip)) return true;
-		if (__builtin_amdgcn_readlane(endw, c)) return true;
-	}
-	return false;
+	const bool isA = __builtin_amdgcn_inverse_ballot_w64(A), isB = __builtin_amdgcn_inverse_ballot_w64(B);
+	const int Sk = lanes_below(B) + (int)isB - lanes_below(A) - (int)isA;
+	int mn = wave_scan_min(Sk);
+	mn = mn < 0 ? mn : 0;
+	const int need = !isB ? INT_MAX : (Sk - mn > k.max_skip ? 0 : k.max_skip + 1 - Sk);
+	const int s63 = __builtin_amdgcn_readlane(Sk, 63);
+	r.a = s63; r.b = s63 - __builtin_amdgcn_readlane(mn, 63);
+	r.thr = __builtin_amdgcn_readlane(wave_scan_min(need), 63);
+	return r;
 }
 
 template <bool SAMEGAP>
-__device__ __forceinline__ void run_unit_dense(const UnitCtx &c, int64_t room, int w)
+__device__ __forceinline__ void run_unit_dense(const UnitCtx &c, int64_t room, int w, int tid)
 {
 	constexpr int MASK = DN_RING - 1;
 	const int lane = c.lane;
-	const uint32_t sink = DN_SINK + (((uint32_t)w << 6 | (uint32_t)lane) << 2);
+	const uint32_t lane4 = (uint32_t)lane << 2;
+	const uint32_t sink = DN_SINK + ((uint32_t)tid << 2);
 	FastK k;
 	k.L4 = (uint32_t)lane << 4;
 	k.far4 = 0; k.trel = 0;
@@ -195,8 +203,10 @@ __device__ __forceinline__ void run_unit_dense(const UnitCtx &c, int64_t room, i
 	k.max_skip = c.max_skip;
 	k.ms0 = c.max_skip > 0 ? c.max_skip : 0;
 	uint64_t x_carry = 0;
+	uint32_t rb = 0;                                                    // round parity: which half of the exchange area (consecutive rounds
+	                                                                    // alternate, also across anchors: a wave may run one round ahead)
 	for (int tile0 = 0;; tile0 += 64) {
-		// every wave holds the tile's anchors (the same 1 KB, four times from L2: nothing next to a scan)
+		// every wave holds the tile's anchors (the same 1 KB, eight times from L2: nothing next to a scan)
 		const int64_t gi = c.base + tile0 + lane;
 		const bool have = tile0 + lane < room;
 		ulonglong2 an = make_ulonglong2(0, 0);
@@ -219,28 +229,113 @@ __device__ __forceinline__ void run_unit_dense(const UnitCtx &c, int64_t room, i
 			const uint64_t xi = readlane_u64(an.x, ii);
 			const uint32_t qi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)an.y, ii);
 			const int span = span_of_hi((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(an.y >> 32), ii));
-			int max_f = span, max_j = -1, n_skip = 0;                   // (wave 0's; the others only evaluate)
+			// the scan's state between rounds (chain.c:251); every wave keeps the same copy
+			int max_f = span, max_j = -1, n_skip = 0;
+			const uint32_t bm = DN_BM;
 			for (int kbr = 0;; kbr += 64 * DN_ROUND) {
-				// the ring (the unit's first anchors find unwritten slots there: they fail the window test), then deep rounds
-				if (kbr == 0) {
+				// ---- this wave's chunks of the round: the ring (the unit's first anchors find unwritten slots there: they fail the
+				// window test), then deep rounds
+				DenseChunk ch[DN_CPW];
+				int excl[DN_CPW];
 #pragma unroll
-					for (int g = 0; g < DN_CPW; ++g) dn_ring_chunk<SAMEGAP>(k, sink, (uint32_t)xi, qi, span - 1, i, DN_CPW * w + g);
-				} else
-					dn_deep_chunks<SAMEGAP>(c, k, sink, xi, qi, span - 1, i, kbr, DN_CPW * w);
-				__syncthreads();
-				if (w == 0) {
-					const bool done = dn_walk_round(k, i, kbr, max_f, max_j, n_skip);
-					if (done) {
-						// anchor i enters the ring (chain.c:283); its marks are wiped: no distance beyond i - 1 can have been set
-						if (lane == ii) lds_store_b128(waddr, make_uint4((uint32_t)an.x + 1u, (uint32_t)an.y + 1u, (uint32_t)max_f, (uint32_t)(max_j << 2)));
-						const uint32_t n_b = (uint32_t)(i + 31) >> 5 << 2;
-						for (uint32_t o = (uint32_t)lane << 4; o < n_b; o += 1024u) lds_store_b128(DN_BM + o, make_uint4(0u, 0u, 0u, 0u));
-					}
-					if (lane == 0) lds_store_b32(DN_RES, done ? 1 : 0);
+				for (int g = 0; g < DN_CPW; ++g) {
+					const int kb = kbr + 64 * (DN_CPW * w + g);
+					ch[g] = kbr == 0 ? dn_ring_chunk<SAMEGAP>(k, bm, sink, (uint32_t)xi, qi, span - 1, i, kb)
+					                 : dn_deep_chunk<SAMEGAP>(c, k, bm, sink, xi, qi, span - 1, i, kb);
+				}
+#pragma unroll
+				for (int g = 0; g < DN_CPW; ++g) {
+					excl[g] = wave_excl_max_floor0(ch[g].sc);
+					const int m63 = max(__builtin_amdgcn_readlane(excl[g], 63), __builtin_amdgcn_readlane(ch[g].sc, 63));
+					lds_store_b32(DN_SC + rb * DN_SC_HALF + 256u * (uint32_t)(DN_CPW * w + g) + lane4, ch[g].sc);
+					if (lane == 0) lds_store_b32(DN_M + rb * DN_M_HALF + 4u * (uint32_t)(DN_CPW * w + g), m63);
 				}
 				__syncthreads();
-				if (__builtin_amdgcn_readfirstlane(lds_load_b32(DN_RES))) break;
+				// ---- with the maxima of the chunks in front: new running maxima (chain.c:274), marked and not better (chain.c:277),
+				// and the chunk's n_skip walk as a function of the n_skip it starts from
+				{
+					const int mv = dn_scan8_max(lane < DN_ROUND ? lds_load_b32(DN_M + rb * DN_M_HALF + lane4) : INT_MIN);
+#pragma unroll
+					for (int g = 0; g < DN_CPW; ++g) {
+						const int cs = DN_CPW * w + g;                                  // the chunk's slot in the round
+						const int before = cs ? __builtin_amdgcn_readlane(mv, cs - 1) : INT_MIN;
+						const int e = max(excl[g], max(before, max_f));
+						const uint64_t A = __builtin_amdgcn_ballot_w64(ch[g].sc > e);   // masked lanes hold INT_MIN
+						const uint64_t B = ch[g].okm & ~A & dn_marked(bm, (uint32_t)(kbr + 64 * cs));
+						const int hiA = highest_lane(A);
+						const DenseWalk wk = dn_chunk_walk(k, A, B, hiA);
+						const int scA = A ? __builtin_amdgcn_readlane(ch[g].sc, hiA) : 0;
+						if (lane == 0) {
+							const uint32_t sa = DN_SUM + rb * DN_SUM_HALF + DN_SUM_CHUNK * (uint32_t)cs;
+							lds_store_b128(sa, make_uint4((uint32_t)wk.a, (uint32_t)wk.b, (uint32_t)wk.thr, (A ? 1u : 0u) | (ch[g].ends ? 2u : 0u) | (wk.inter ? 4u : 0u)));
+							lds_store_b128(sa + 16u, make_uint4((uint32_t)scA, (uint32_t)hiA, 0u, 0u));
+							lds_store_b128(sa + 32u, make_uint4((uint32_t)A, (uint32_t)(A >> 32), (uint32_t)B, (uint32_t)(B >> 32)));
+						}
+					}
+				}
+				__syncthreads();
+				// ---- the round's eight walks composed, a lane per chunk (every wave does this for itself -- same numbers, no broadcast:
+				// a third barrier per round costs more than seven redundant copies of these ~70 instructions)
+				bool done;
+				{
+					uint4 s0 = make_uint4(0u, (uint32_t)DN_NEG, (uint32_t)INT_MAX, 0u);
+					int2 s1 = make_int2(0, 0);
+					if (lane < DN_ROUND) {
+						const uint32_t sa = DN_SUM + rb * DN_SUM_HALF + DN_SUM_CHUNK * (uint32_t)lane;
+						s0 = lds_load_b128(sa); s1 = lds_load_b64(sa + 16u);
+					}
+					// inclusive composition over the lanes: (a1, b1) then (a2, b2) is (a1 + a2, max(b1 + a2, b2))
+					int ca = (int)s0.x, cb = (int)s0.y;
+#pragma unroll
+					for (int sh = 1; sh < DN_ROUND; sh <<= 1) {
+						int la, lb;
+						if (sh == 1) { la = dpp_or_old<DPP_ROW_SHR(1), 0xf>(0, ca); lb = dpp_or_old<DPP_ROW_SHR(1), 0xf>(DN_NEG, cb); }
+						else if (sh == 2) { la = dpp_or_old<DPP_ROW_SHR(2), 0xf>(0, ca); lb = dpp_or_old<DPP_ROW_SHR(2), 0xf>(DN_NEG, cb); }
+						else { la = dpp_or_old<DPP_ROW_SHR(4), 0xf>(0, ca); lb = dpp_or_old<DPP_ROW_SHR(4), 0xf>(DN_NEG, cb); }
+						cb = max(lb + ca, cb); ca = la + ca;
+					}
+					const int x_out = max(n_skip + ca, cb);                             // n_skip behind chunk `lane`
+					const int x_in = dpp_or_old<DPP_ROW_SHR(1), 0xf>(n_skip, x_out);    // ... and in front of it
+					const bool brk = lane < DN_ROUND && x_in >= (int)s0.z;
+					const uint64_t brkm = __builtin_amdgcn_ballot_w64(brk);
+					const uint64_t stopm = brkm | __builtin_amdgcn_ballot_w64(lane < DN_ROUND && (s0.w & 2u));
+					done = stopm != 0;
+					const int cstar = done ? __builtin_ctzll(stopm) : DN_ROUND - 1;      // the chunk the scan ends in (or the round's last)
+					const uint64_t hasm = __builtin_amdgcn_ballot_w64(lane < DN_ROUND && (s0.w & 1u));
+					const bool exact = done && (brkm >> cstar & 1ull) && (__builtin_amdgcn_readlane((int)s0.w, cstar) & 4);
+					// the running maximum: the last chunk up to cstar with a new maximum.  If the break falls into a chunk whose A and B
+					// lanes interleave, only the A lanes in front of the break count: that chunk is walked lane by lane below.
+					const uint64_t cand = hasm & low_mask64(__builtin_amdgcn_readfirstlane(exact ? cstar : cstar + 1));
+					if (cand) {
+						const int cc = 63 - __builtin_clzll(cand);
+						max_f = __builtin_amdgcn_readlane(s1.x, cc);
+						max_j = i - 1 - kbr - 64 * cc - __builtin_amdgcn_readlane(s1.y, cc);
+					}
+					if (__builtin_expect(exact, 0)) {
+						FastMasks m;
+						const uint32_t sa = DN_SUM + rb * DN_SUM_HALF + DN_SUM_CHUNK * (uint32_t)cstar + 32u;
+						const uint4 ab = lds_load_b128(sa);
+						m.A = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)ab.y) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((int)ab.x);
+						m.B = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)ab.w) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((int)ab.z);
+						m.sc = lds_load_b32(DN_SC + rb * DN_SC_HALF + 256u * (uint32_t)cstar + lane4);
+						m.drm1 = 0;
+						int ns = __builtin_amdgcn_readlane(x_in, cstar);
+						(void)fast_walk_general(k, m, i - 1 - kbr - 64 * cstar, max_f, max_j, ns);
+					}
+					n_skip = __builtin_amdgcn_readlane(x_out, DN_ROUND - 1);
+				}
+				rb ^= 1u;
+				if (done) break;
 			}
+			// anchor i enters the ring (chain.c:283); its marks are wiped: no distance beyond i - 1 can have been set.  (Measured
+			// against this: a second bitmap wiped during the next anchor instead of this barrier, same time for one unit per CU and
+			// 18 % more with several; one walking wave that tells the others, i.e. a third barrier per round, 10-20 % more.)
+			if (w == 0 && lane == ii) lds_store_b128(waddr, make_uint4((uint32_t)an.x + 1u, (uint32_t)an.y + 1u, (uint32_t)max_f, (uint32_t)(max_j << 2)));
+			{
+				const uint32_t n_b = (uint32_t)(i + 31) >> 5 << 2;
+				for (uint32_t q = (uint32_t)tid << 4; q < n_b; q += 1024u * DN_WAVES) lds_store_b128(DN_BM + q, make_uint4(0u, 0u, 0u, 0u));
+			}
+			__syncthreads();
 		}
 		// wave 0 flushes the tile (v of chain.c:284, f/p/v, the compaction helpers) while the others start on the next one
 		if (w == 0) fast_flush_tile<DN_RING>(c, tile0, cnt, waddr, gi);
@@ -273,10 +368,10 @@ __global__ __launch_bounds__(64 * DN_WAVES) void k_chain_dense(DenseArgs g)
 			for (int q = tid; q * 8 < g.lut_stride; q += 64 * DN_WAVES) lds_store_b128(DN_LUT + ((uint32_t)q << 4), src[q]);
 			const uint32_t x_none = (uint32_t)g.a[u.start].x - (uint32_t)c.maxx - 1u;    // "no anchor here yet" (x+1 encoding): fails the window test
 			for (int q = tid; q < DN_RING; q += 64 * DN_WAVES) lds_store_b128((uint32_t)q << 4, make_uint4(x_none, 0u, 0u, 0xfffffffcu));
-			for (uint32_t o = (uint32_t)tid << 4; o < CHAINDP_DENSE_BITCAP / 8u; o += 1024u * DN_WAVES) lds_store_b128(DN_BM + o, make_uint4(0u, 0u, 0u, 0u));
+			for (uint32_t o = (uint32_t)tid << 4; o < DN_BM_BYTES; o += 1024u * DN_WAVES) lds_store_b128(DN_BM + o, make_uint4(0u, 0u, 0u, 0u));
 		}
 		__syncthreads();
-		run_unit_dense<SAMEGAP>(c, (int64_t)u.len, w);
+		run_unit_dense<SAMEGAP>(c, (int64_t)u.len, w, tid);
 	}
 }
 

@@ -50,13 +50,18 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
                         const Unit *d_units, const unsigned long long *d_counters,
                         int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags,
                         const Unit *d_units_all = nullptr, const unsigned long long *d_counters_all = nullptr,
-                        Unit *d_deep = nullptr, unsigned int *d_deep_cnt = nullptr);
+                        Unit *d_deep = nullptr, unsigned int *d_deep_cnt = nullptr, const unsigned int *d_long_units = nullptr);
+// *d_long_units: units of CHAINDP_LONG_UNIT anchors and more in the batch (PrepassScratch::hist + CHAINDP_LONG_UNIT_CLASS, valid
+// after launch_prepass); above CHAINDP_DENSE_MAX_LONG of them nothing is handed over
+#define CHAINDP_LONG_UNIT_CLASS 65      // hist[c] after k_unit_bases = units in length classes above c; class 65 ends at 8191 anchors
+#define CHAINDP_DENSE_MAX_LONG 4096u
 // Units whose scans keep reaching past the ring (dense repeats) are appended to d_deep / *d_deep_cnt by the launch above (when
 // given) and redone by k_chain_dense (chaindp_dense.hip): a workgroup of four waves per unit, marks as one bit per distance in
 // LDS.  The low 32 bits of *d_deep_cnt are the count.  Only units of at most CHAINDP_DENSE_BITCAP anchors are handed over (the
 // bitmap covers that many distances), and only while 32-bit differences are exact over a ring of CHAINDP_DENSE_RING anchors.
 #define CHAINDP_DENSE_BITCAP 65536
 #define CHAINDP_DENSE_RING 512
+#define CHAINDP_DENSE_UNITS 2048u      // units handed over per batch (about two rounds of workgroups on the chip)
 hipError_t launch_chain_dense(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
                               const uint16_t *d_lut, int lut_stride, const Unit *d_deep, const unsigned long long *d_deep_cnt,
                               int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags);
