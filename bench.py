@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads-per-gpu", type=int, default=READS_PER_GPU)
-    ap.add_argument("--preset", default="ava-ont", help="generator + DP preset (ava-ont, map-ont, skew)")
+    ap.add_argument("--preset", default="ava-ont", help="generator + DP preset (ava-ont, map-ont, skew, dense)")
     ap.add_argument("--ring", type=int, default=0, help="LDS ring capacity override (128/256/512)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -193,7 +193,10 @@ def other_configs(chaindp, params, shard, dev_index, args):
     of configs[3] (100,000 reads, ~0.6 G anchors, ~10 GB of anchors) on one GPU.  Reported beside the headline, never as `value`."""
     out = {}
     for name, gen, preset, reads in (("map_ont_50M", "map-ont", "map-ont", 9_400), ("skew_1e2_1e5", "skew", "ava-ont", 3_000),
-                                     ("full_100k_reads_1gpu", "ava-ont", "ava-ont", 100_000)):
+                                     ("full_100k_reads_1gpu", "ava-ont", "ava-ont", 100_000),
+                                     # dense repeats (scans of hundreds to tens of thousands of predecessors): a batch that is all
+                                     # tail -- 200 units of 15-38 k anchors -- and ten times that
+                                     ("dense_200_units", "dense", "ava-ont", 100), ("dense_2000_units", "dense", "ava-ont", 1_000)):
         try:
             par = params.preset(preset)
             off, a = shard.generate_shard(gen, 0, 1, reads, SEED, threads=args.host_threads)
@@ -215,7 +218,16 @@ def other_configs(chaindp, params, shard, dev_index, args):
                 out[name] = {"generator": gen, "dp_preset": preset, "reads": reads, "anchors": tot, "units": st["units"], "steps": n,
                              "ms_per_step": dt / n * 1e3, "anchors_per_s": tot * n / dt,
                              "kernel_ms": {kk: k[kk][0] / max(k[kk][1], 1) for kk in ("prepass", "chain_dp", "compact")},
-                             "handed_to_one_unit_per_wave_kernel": d.leftover_units()}
+                             "handed_to_one_unit_per_wave_kernel": d.leftover_units(), "handed_to_dense_kernel": d.deep_units()}
+                if gen == "dense":                                   # the same batch with every unit left to its one wave (k_chain_units)
+                    d.set_deep_handover(False)
+                    d.run_full(par); d.sync()
+                    t0 = time.perf_counter()
+                    for _ in range(2):
+                        d.run_full(par)
+                    d.sync()
+                    out[name]["ms_per_step_one_wave_per_unit"] = (time.perf_counter() - t0) / 2 * 1e3
+                    out[name]["speedup_from_dense_kernel"] = out[name]["ms_per_step_one_wave_per_unit"] / out[name]["ms_per_step"]
             del off, a
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": repr(e)}
@@ -248,7 +260,33 @@ def measure_map_batch(chaindp, params, dev_index, target_anchors=24_000_000):
             for _ in range(n):
                 roff, regs, rep, na = d.map_batch(ix, int(g["flag"]), int(g["mid_occ"]), par, pv[7], mini_off, mini, bid, qlen, hash_, regs_cap=cap_a // 8)
             dt = (time.perf_counter() - t0) / n
-        return {"input": os.path.relpath(path, ROOT), "repeated": mult, "reads": n_reads, "minimizers": int(mini_off[-1]), "anchors": na,
+            # ... and the same call from three host threads, a context each, the index image shared: while one context waits for its
+            # seed counts or downloads its hits, the other two have kernels on the GPU (what the packet shim's service contexts do)
+            conc = None
+            try:
+                import threading
+                n_ctx, n_each = 3, 4
+                devs = [chaindp.Device(dev_index, max_anchors=cap_a, max_reads=n_reads + 1) for _ in range(n_ctx)]
+                try:
+                    def work(dd, k):
+                        for _ in range(k):
+                            dd.map_batch(ix, int(g["flag"]), int(g["mid_occ"]), par, pv[7], mini_off, mini, bid, qlen, hash_, regs_cap=cap_a // 8)
+                    for dd in devs:
+                        work(dd, 1)                                   # first use: allocations
+                    th = [threading.Thread(target=work, args=(dd, n_each)) for dd in devs]
+                    t0 = time.perf_counter()
+                    for t in th:
+                        t.start()
+                    for t in th:
+                        t.join()
+                    dtc = time.perf_counter() - t0
+                    conc = {"contexts": n_ctx, "batches": n_ctx * n_each, "seconds": dtc, "anchors_per_s": na * n_ctx * n_each / dtc}
+                finally:
+                    for dd in devs:
+                        dd.close()
+            except Exception as e:  # noqa: BLE001
+                conc = {"error": repr(e)}
+        return {"three_contexts": conc, "input": os.path.relpath(path, ROOT), "repeated": mult, "reads": n_reads, "minimizers": int(mini_off[-1]), "anchors": na,
                 "hits": int(roff[-1]), "seconds_per_batch": dt, "anchors_per_s": na / dt, "minimizers_per_s": int(mini_off[-1]) / dt,
                 "bytes_in_per_anchor": (16 * int(mini_off[-1]) + 20 * n_reads) / max(na, 1), "bytes_out_per_anchor": (80 * int(roff[-1]) + 12 * n_reads) / max(na, 1),
                 "includes": "H2D of minimizers (pageable), collect_seed_hits + sort, prepass + chain DP + compaction, backtrack, mm_gen_regs, D2H of hits"}

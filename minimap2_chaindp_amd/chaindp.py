@@ -325,10 +325,11 @@ class Device:
         return int(self._lib.chaindp_debug_deep_units(self._ctx))
 
     def set_deep_handover(self, on=True):
-        """Test hook: False keeps every unit in the launch that took it (k_chain_units then serves long scans from HBM/L2)."""
+        """Test hook: False keeps every unit in the launch that took it (k_chain_units then serves long scans from HBM/L2); 2 hands
+        over any unit with a few deep scans, whatever its length (small test inputs reach k_chain_dense)."""
         self._lib.chaindp_debug_set_deep_handover.restype = C.c_int
         self._lib.chaindp_debug_set_deep_handover.argtypes = [C.c_void_p, C.c_int]
-        self._check(self._lib.chaindp_debug_set_deep_handover(self._ctx, int(bool(on))))
+        self._check(self._lib.chaindp_debug_set_deep_handover(self._ctx, 2 if on == 2 else int(bool(on))))
 
     def stats(self):
         st = (C.c_int64 * 4)()

@@ -39,6 +39,7 @@ struct chaindp_ctx {
 	Unit *d_left = nullptr;               // units the two-per-wave kernel hands over to k_chain_units
 	unsigned long long *d_left_cnt = nullptr;   // [0] handed-over count | the twin kernel's queue << 32; [1] count of d_deep
 	Unit *d_deep = nullptr;               // units k_chain_units hands over to its k_chain_dense (scans that keep reaching past the ring)
+	int deep_eager = 0;                   // test hook: hand over any unit with a few deep scans, whatever its length
 	bool deep_handover = true;            // CHAINDP_NO_DEEP_HANDOVER (diagnostic / A-B): every unit stays in the launch that took it
 	int variant = 0;                      // 0: k_chain_twin + k_chain_units for the rest; 1: k_chain_units, general variant; 2: k_chain_units only
 	unsigned long long *d_counters = nullptr;
@@ -270,11 +271,11 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		const int64_t left_grid = total / 2 < 32768 ? total / 2 : 32768;
 		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, left_grid, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_left,
 		                                   ctx->d_left_cnt, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
-		                                   ctx->d_units, ctx->d_counters, deep, deep_cnt, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS));
+		                                   ctx->d_units, ctx->d_counters, deep, deep_cnt, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_eager));
 	} else
 		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, total / 2, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_units,
 		                                   ctx->d_counters, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
-		                                   nullptr, nullptr, deep, deep_cnt, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS));
+		                                   nullptr, nullptr, deep, deep_cnt, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_eager));
 	// units whose scans kept reaching past the ring (dense repeats): redone by k_chain_dense
 	if (deep && lut)
 		HIP_TRY(ctx, chaindp::launch_chain_dense(st, q, total / 128 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,
@@ -584,11 +585,13 @@ extern "C" int64_t chaindp_debug_leftover(chaindp_ctx_t *ctx)
 }
 
 // test hook (not in the public header): 0 keeps every unit in the launch that took it (the deep path of the small rings stays
-// covered by the parity tests), 1 (default) hands units whose scans keep reaching past the ring to the k_chain_dense
+// covered by the parity tests), 1 (default) hands long units whose scans keep reaching past the ring to k_chain_dense, 2 any unit
+// with a few such scans (small test inputs reach k_chain_dense)
 extern "C" int chaindp_debug_set_deep_handover(chaindp_ctx_t *ctx, int on)
 {
 	if (!ctx) return CHAINDP_ERR_ARG;
 	ctx->deep_handover = on != 0;
+	ctx->deep_eager = on == 2;
 	return CHAINDP_OK;
 }
 

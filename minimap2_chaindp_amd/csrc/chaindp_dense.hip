@@ -1,4 +1,4 @@
-// chaindp_dense.hip -- the chain DP kernel for units whose scans run deep (dense repeats): k_chain_dense, FOUR waves per unit.
+// chaindp_dense.hip -- the chain DP kernel for units whose scans run deep (dense repeats): k_chain_dense, EIGHT waves per unit.
 //
 // In a dense repeat the window of chain.c:252 holds hundreds to thousands of predecessors and few of them get marked, so
 // the scan of chain.c:253-282 does not end at the (max_skip + 1)-th marked predecessor after ~30 steps but walks on: a
@@ -8,20 +8,23 @@
 // 0.3 s, sixty times the whole 76 M-anchor benchmark batch).  k_chain_units hands a unit that keeps scanning past its
 // LDS ring over to this kernel (CHAINDP_DEEP_HANDOVER), which computes exactly the same thing (run_unit_fast of
 // chaindp_kernels.hip, reference chain.c:246-284 for one-segment, non-cDNA reads) in a different shape:
-//   * a workgroup of four waves per unit, one on each SIMD of a CU.  A scan proceeds in ROUNDS of eight 64-lane chunks
-//     (512 predecessors; the first round is the LDS ring, the following ones come back from HBM/L2); each wave evaluates
-//     two chunks of the round -- filters, scores, the chunk's own prefix max, marks -- which is everything that does not
-//     depend on the chunks in front, and leaves score, prefix max and the lane mask of passing
-//     predecessors in LDS.  After a barrier wave 0 applies the serial semantics (chain.c:274-279) chunk by chunk with
-//     fast_walk, as k_chain_units does, and says whether the scan goes on; a second barrier ends the round.  Chunks
+//   * a workgroup of eight waves per unit.  A scan proceeds in ROUNDS of eight 64-lane chunks (512 predecessors; the
+//     first round is the LDS ring, the following ones come back from HBM/L2), a chunk per wave.  What a chunk contributes
+//     before the serial semantics -- filters, scores, its own prefix max, marks -- does not depend on the chunks in front
+//     (DESIGN.md section 4): the waves do that side by side and exchange the chunks' maxima (barrier).  With the maxima in
+//     front of it a wave knows its chunk's new running maxima (chain.c:274) and marked non-improving lanes (chain.c:277),
+//     hence its n_skip walk (chain.c:276-279) as a FUNCTION of the n_skip it starts from: x -> max(x + a, b), break iff
+//     x >= thr -- two popcounts when every new maximum precedes every marked lane, a prefix min otherwise.  The eight
+//     functions go to LDS (barrier), and every wave composes them with a three-step lane-parallel prefix ((a1, b1) then
+//     (a2, b2) = (a1 + a2, max(b1 + a2, b2))), finds the chunk the scan ends in and the running maximum there.  Chunks
 //     behind the break are evaluated for nothing; the marks they write are never read;
 //   * marks by distance as ONE BIT each: bit d of an LDS bitmap = "the predecessor d + 1 behind the current anchor is
 //     marked" (chain.c:281).  64 K distances are 8 KB, so marks never leave LDS whatever the depth
-//     of the scan: a mark is one ds_or_b32, a chunk's "marked" lane mask (chain.c:277) is one 64-bit word, and wave 0
-//     wipes the bitmap after each anchor up to the anchor's index.  (Units of more than 64 K anchors stay with
-//     k_chain_units.)
-// The LDS footprint is per unit (27 KB: five units, twenty waves per CU), so the four waves also buy the occupancy that
-// one wave per unit cannot have.
+//     of the scan: a mark is one ds_or_b32, a chunk's "marked" lane mask is one 64-bit word, and the workgroup wipes the
+//     bitmap after each anchor up to the anchor's index.  (Units of more than 64 K anchors stay with k_chain_units.)
+// The LDS footprint is per unit (29 KB), so the eight waves also buy the occupancy one wave per unit cannot have (four units,
+// 32 waves per CU).  Measured (tools/dense_probe.py, MI355X): 200 dense units of 15-38 k anchors 310 -> 108 ms, 2000 units
+// 526 -> 277 ms; a batch of thousands of long units is bound by instruction count, not by its tail, and is not handed over.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>

@@ -39,11 +39,15 @@ struct UnitCtx {
 	// scans of the current unit that went past the ring so far (nullptr: this launch keeps every unit)
 	Unit *deep_list;
 	unsigned int *deep_cnt;
+	int deep_min, deep_left;        // CHAINDP_DEEP_HANDOVER, CHAINDP_DEEP_HANDOVER_LEFT (tests: 8, 0 -- any unit with a few deep scans)
 	mutable int deep_n;
 };
 
-// scans past the ring after which k_chain_units hands a table-driven unit to k_chain_dense
-#define CHAINDP_DEEP_HANDOVER 8
+// k_chain_units hands a table-driven unit to k_chain_dense once this many of its scans went past the ring, if that is at
+// least every second anchor so far and the unit may have this many anchors left: the unit starts over there, and a short unit
+// or one with the odd deep scan (ordinary ava-ont batches have a handful) would only become a tail of its own behind the launch
+#define CHAINDP_DEEP_HANDOVER 64
+#define CHAINDP_DEEP_HANDOVER_LEFT 2048
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef int i32x2_t __attribute__((ext_vector_type(2)));

@@ -50,7 +50,8 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
                         const Unit *d_units, const unsigned long long *d_counters,
                         int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags,
                         const Unit *d_units_all = nullptr, const unsigned long long *d_counters_all = nullptr,
-                        Unit *d_deep = nullptr, unsigned int *d_deep_cnt = nullptr, const unsigned int *d_long_units = nullptr);
+                        Unit *d_deep = nullptr, unsigned int *d_deep_cnt = nullptr, const unsigned int *d_long_units = nullptr,
+                        int deep_eager = 0);   // tests: hand over any unit with a few deep scans
 // *d_long_units: units of CHAINDP_LONG_UNIT anchors and more in the batch (PrepassScratch::hist + CHAINDP_LONG_UNIT_CLASS, valid
 // after launch_prepass); above CHAINDP_DENSE_MAX_LONG of them nothing is handed over
 #define CHAINDP_LONG_UNIT_CLASS 65      // hist[c] after k_unit_bases = units in length classes above c; class 65 ends at 8191 anchors

@@ -543,7 +543,7 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 		// what this wave has stored so far is what that kernel stores again.
 		// Only the first CHAINDP_DENSE_UNITS units to get here (units run longest first) are handed over: k_chain_dense shortens
 		// the batch's tail; a batch that is dense all over is bound by instruction count, and there eight waves per unit lose.
-		if (c.deep_list && c.deep_n >= CHAINDP_DEEP_HANDOVER && tile0 + 64 < room && room <= CHAINDP_DENSE_BITCAP &&
+		if (c.deep_list && c.deep_n >= c.deep_min && (2 * c.deep_n >= tile0 + 64 || c.deep_left == 0) && room - tile0 >= c.deep_left && tile0 + 64 < room && room <= CHAINDP_DENSE_BITCAP &&
 		    (unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c.deep_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < CHAINDP_DENSE_UNITS) {
 			if (lane == 0) { Unit un; un.start = c.base; un.read = c.read; un.len = (int32_t)room; c.deep_list[atomicAdd(c.deep_cnt, 1u)] = un; }
 			return;
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                     int32_t *f, int32_t *p, int32_t *v, unsigned long long *tg, uint32_t epoch,
                                                     int32_t *first_child, uint8_t *flags,
                                                     const Unit *__restrict__ units_all, const unsigned long long *__restrict__ counters_all,
-                                                    Unit *deep_list, unsigned int *deep_cnt, const unsigned int *__restrict__ long_units)
+                                                    Unit *deep_list, unsigned int *deep_cnt, const unsigned int *__restrict__ long_units, int deep_eager)
 {
 	static_assert((RING & (RING - 1)) == 0 && RING >= 128, "RING must be a power of two >= 128");
 	extern __shared__ uint4 smem[];
@@ -582,6 +582,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 	// from the prepass' length classes) every SIMD is busy to the end anyway and the batch is bound by instruction count, where
 	// eight waves per unit lose (measured: 8000 dense units 0.24 G anchors/s here, 0.20 there)
 	if (long_units && *long_units > CHAINDP_DENSE_MAX_LONG) c.deep_list = nullptr;
+	c.deep_min = deep_eager ? 8 : CHAINDP_DEEP_HANDOVER; c.deep_left = deep_eager ? 0 : CHAINDP_DEEP_HANDOVER_LEFT;
 	c.deep_cnt = deep_cnt;
 	c.maxx = (uint64_t)(int64_t)par.max_dist_x;
 	c.mdx = par.max_dist_x; c.mdy = par.max_dist_y; c.bw = par.bw; c.max_skip = par.max_skip; c.is_cdna = par.is_cdna;
@@ -635,7 +636,7 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
                         const Unit *d_units, const unsigned long long *d_counters,
                         int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags,
                         const Unit *d_units_all, const unsigned long long *d_counters_all, Unit *d_deep, unsigned int *d_deep_cnt,
-                        const unsigned int *d_long_units)
+                        const unsigned int *d_long_units, int deep_eager)
 {
 	if (max_units <= 0) return hipSuccess;
 	// The number of units is only known on the device (counters[0]); the grid is sized for the upper
@@ -655,9 +656,9 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
 		if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
 	}
 	switch (ring) {
-	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt, d_long_units); break;
-	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt, d_long_units); break;
-	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt, d_long_units); break;
+	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt, d_long_units, deep_eager); break;
+	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt, d_long_units, deep_eager); break;
+	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt, d_long_units, deep_eager); break;
 	}
 	return hipGetLastError();
 }

@@ -115,7 +115,7 @@ def test_large_bw_takes_the_general_path(dev):
     dict(max_skip=-1, max_dist_y=700),
 ])
 @pytest.mark.parametrize("gen,n_reads", [("dense", 2), ("ties", 40)])
-@pytest.mark.parametrize("ring,handover", [(128, False), (512, False), (128, True), (256, True)])
+@pytest.mark.parametrize("ring,handover", [(128, False), (512, False), (128, 2), (256, 2)])
 def test_fast_variant_parameter_corners(dev, par_over, gen, n_reads, ring, handover):
     """The table-driven variant folds the window, gap and bandwidth tests of chain.c:252-260 into one unsigned compare and keeps
     marks by distance; 'dense' walks the whole window (ring chunks, far marks, the deep path), 'ties' breaks early.  Without the
@@ -140,7 +140,7 @@ def test_fast_variant_parameter_corners(dev, par_over, gen, n_reads, ring, hando
         dev.set_ring(128)
 
 
-@pytest.mark.parametrize("gen_kw", [dict(read_len=3000, n_hits=12), dict(read_len=700, n_hits=40), dict(read_len=6000, n_hits=6)])
+@pytest.mark.parametrize("gen_kw", [dict(read_len=3000, n_hits=12), dict(read_len=4000, n_hits=20), dict(read_len=6000, n_hits=6)])
 def test_dense_units_are_redone_by_the_dense_kernel(dev, gen_kw):
     """Default settings: units whose scans keep reaching past the LDS ring (dense repeats) are handed by k_chain_units to
     k_chain_dense, which redoes them from scratch -- same f/p/v and new_seed[] as the oracle."""
