@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "chaindp_kernels.h"
 #include "chaindp_wave.h"
 #include "chaindp_fast.h"
@@ -73,7 +75,16 @@ struct DenseArgs {
 	int32_t *f, *p, *v;
 	int32_t *first_child;
 	uint8_t *flags;
+	unsigned long long *stamp;          // diagnostic build (-DCHAINDP_DENSE_STAMPS, run with CHAINDP_DENSE_STAMP=1): where wave 0's time goes
 };
+
+// in-kernel stamps: compiled in only with -DCHAINDP_DENSE_STAMPS (make -C csrc stamps)
+#ifdef CHAINDP_DENSE_STAMPS
+#define DN_STAMP(...) __VA_ARGS__
+#else
+#define DN_STAMP(...)
+#endif
+#define DN_NOW() __builtin_amdgcn_s_memtime()
 
 __device__ __forceinline__ void dn_or_b32(uint32_t a, uint32_t v)
 {
@@ -190,7 +201,7 @@ __device__ __forceinline__ DenseWalk dn_chunk_walk(const FastK &k, uint64_t A, u
 }
 
 template <bool SAMEGAP>
-__device__ __forceinline__ void run_unit_dense(const UnitCtx &c, int64_t room, int w, int tid)
+__device__ __forceinline__ void run_unit_dense(const UnitCtx &c, int64_t room, int w, int tid, unsigned long long *stamp_out)
 {
 	constexpr int MASK = DN_RING - 1;
 	const int lane = c.lane;
@@ -205,6 +216,7 @@ __device__ __forceinline__ void run_unit_dense(const UnitCtx &c, int64_t room, i
 	k.dq_off = k.M - (uint32_t)c.mdq;
 	k.max_skip = c.max_skip;
 	k.ms0 = c.max_skip > 0 ? c.max_skip : 0;
+	DN_STAMP(unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long t_unit0 = DN_NOW();)
 	uint64_t x_carry = 0;
 	uint32_t rb = 0;                                                    // round parity: which half of the exchange area (consecutive rounds
 	                                                                    // alternate, also across anchors: a wave may run one round ahead)
@@ -236,6 +248,7 @@ __device__ __forceinline__ void run_unit_dense(const UnitCtx &c, int64_t room, i
 			int max_f = span, max_j = -1, n_skip = 0;
 			const uint32_t bm = DN_BM;
 			for (int kbr = 0;; kbr += 64 * DN_ROUND) {
+				DN_STAMP(const unsigned long long ta0 = DN_NOW();)
 				// ---- this wave's chunks of the round: the ring (the unit's first anchors find unwritten slots there: they fail the
 				// window test), then deep rounds
 				DenseChunk ch[DN_CPW];
@@ -253,7 +266,9 @@ __device__ __forceinline__ void run_unit_dense(const UnitCtx &c, int64_t room, i
 					lds_store_b32(DN_SC + rb * DN_SC_HALF + 256u * (uint32_t)(DN_CPW * w + g) + lane4, ch[g].sc);
 					if (lane == 0) lds_store_b32(DN_M + rb * DN_M_HALF + 4u * (uint32_t)(DN_CPW * w + g), m63);
 				}
+				DN_STAMP(const unsigned long long tb0 = DN_NOW(); st[0] += tb0 - ta0;)
 				__syncthreads();
+				DN_STAMP(const unsigned long long tb1 = DN_NOW(); st[1] += tb1 - tb0;)
 				// ---- with the maxima of the chunks in front: new running maxima (chain.c:274), marked and not better (chain.c:277),
 				// and the chunk's n_skip walk as a function of the n_skip it starts from
 				{
@@ -276,9 +291,12 @@ __device__ __forceinline__ void run_unit_dense(const UnitCtx &c, int64_t room, i
 						}
 					}
 				}
+				DN_STAMP(const unsigned long long tb2 = DN_NOW(); st[2] += tb2 - tb1;)
 				__syncthreads();
+				DN_STAMP(st[3] += DN_NOW() - tb2;)
 				// ---- the round's eight walks composed, a lane per chunk (every wave does this for itself -- same numbers, no broadcast:
 				// a third barrier per round costs more than seven redundant copies of these ~70 instructions)
+				DN_STAMP(const unsigned long long tc0 = DN_NOW();)
 				bool done;
 				{
 					uint4 s0 = make_uint4(0u, (uint32_t)DN_NEG, (uint32_t)INT_MAX, 0u);
@@ -327,6 +345,7 @@ __device__ __forceinline__ void run_unit_dense(const UnitCtx &c, int64_t room, i
 					}
 					n_skip = __builtin_amdgcn_readlane(x_out, DN_ROUND - 1);
 				}
+				DN_STAMP(st[4] += DN_NOW() - tc0; ++st[8]; if (kbr) ++st[9];)
 				rb ^= 1u;
 				if (done) break;
 			}
@@ -338,12 +357,17 @@ __device__ __forceinline__ void run_unit_dense(const UnitCtx &c, int64_t room, i
 				const uint32_t n_b = (uint32_t)(i + 31) >> 5 << 2;
 				for (uint32_t q = (uint32_t)tid << 4; q < n_b; q += 1024u * DN_WAVES) lds_store_b128(DN_BM + q, make_uint4(0u, 0u, 0u, 0u));
 			}
+			DN_STAMP(const unsigned long long te0 = DN_NOW();)
 			__syncthreads();
+			DN_STAMP(st[5] += DN_NOW() - te0; ++st[7];)
 		}
 		// wave 0 flushes the tile (v of chain.c:284, f/p/v, the compaction helpers) while the others start on the next one
+		DN_STAMP(const unsigned long long tf0 = DN_NOW();)
 		if (w == 0) fast_flush_tile<DN_RING>(c, tile0, cnt, waddr, gi);
+		DN_STAMP(st[6] += DN_NOW() - tf0;)
 		if (cnt < 64) break;
 	}
+	DN_STAMP(if (stamp_out && w == 0 && lane == 0) { for (int q = 0; q < 10; ++q) atomicAdd(stamp_out + q, st[q]); atomicAdd(stamp_out + 10, DN_NOW() - t_unit0); })
 }
 
 template <bool SAMEGAP>
@@ -374,7 +398,7 @@ __global__ __launch_bounds__(64 * DN_WAVES) void k_chain_dense(DenseArgs g)
 			for (uint32_t o = (uint32_t)tid << 4; o < DN_BM_BYTES; o += 1024u * DN_WAVES) lds_store_b128(DN_BM + o, make_uint4(0u, 0u, 0u, 0u));
 		}
 		__syncthreads();
-		run_unit_dense<SAMEGAP>(c, (int64_t)u.len, w, tid);
+		run_unit_dense<SAMEGAP>(c, (int64_t)u.len, w, tid, g.stamp);
 	}
 }
 
@@ -408,8 +432,26 @@ hipError_t launch_chain_dense(hipStream_t st, const Params &par, int64_t max_uni
 	DenseArgs g;
 	g.par = par; g.off = d_off; g.a = (const ulonglong2*)d_a; g.lut = d_lut; g.lut_stride = lut_stride;
 	g.units = d_deep; g.count = d_deep_cnt; g.f = d_f; g.p = d_p; g.v = d_v; g.first_child = d_first_child; g.flags = d_flags;
+	g.stamp = nullptr;
+#ifdef CHAINDP_DENSE_STAMPS
+	static unsigned long long *d_stamp = nullptr;
+	const bool stamp = getenv("CHAINDP_DENSE_STAMP") != nullptr;
+	if (stamp && !d_stamp && hipMalloc((void**)&d_stamp, 16 * 8) != hipSuccess) d_stamp = nullptr;
+	if (stamp && d_stamp) { (void)hipMemsetAsync(d_stamp, 0, 16 * 8, st); g.stamp = d_stamp; }
+#endif
 	if (par.max_dist_y >= par.max_dist_x) hipLaunchKernelGGL(k_chain_dense<true>, dim3((unsigned)blocks), dim3(64 * DN_WAVES), lds, st, g);
 	else hipLaunchKernelGGL(k_chain_dense<false>, dim3((unsigned)blocks), dim3(64 * DN_WAVES), lds, st, g);
+#ifdef CHAINDP_DENSE_STAMPS
+	if (g.stamp) {
+		unsigned long long h[16];
+		if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h, g.stamp, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[7]) {
+			const double na = (double)h[7], nr = (double)h[8];
+			fprintf(stderr, "[dense stamp] wave 0, shader-clock ticks per ANCHOR: total %.0f | evaluate %.0f, barrier %.0f, summarise %.0f, barrier %.0f, compose %.0f, "
+			                "wipe + barrier %.0f, flush %.0f | rounds per anchor %.2f (deep %.2f)\n", (double)h[10] / na, h[0] / na, h[1] / na, h[2] / na, h[3] / na, h[4] / na,
+			        h[5] / na, h[6] / na, nr / na, (double)h[9] / na);
+		}
+	}
+#endif
 	return hipGetLastError();
 }
 
