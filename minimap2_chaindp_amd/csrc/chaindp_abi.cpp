@@ -46,6 +46,7 @@ struct chaindp_ctx {
 	chaindp::PrepassScratch pre = {nullptr, nullptr, nullptr, nullptr, nullptr};
 	chaindp::CompactScratch cmp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	chaindp::BottomScratch bot = {};
+	bool bot_ready = false, seed_ready = false;   // first-use allocations complete
 	std::vector<void*> bot_allocs;
 	uint16_t *d_lut = nullptr;
 	void **d_ptrs = nullptr;         // per-read host pointers for the gather / scatter kernels
@@ -436,20 +437,32 @@ extern "C" int chaindp_backtrack(chaindp_ctx_t *ctx, const chaindp_params_t *par
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	const int64_t m = ctx->total > 0 && ctx->n_reads > 0 ? (int64_t)(uint32_t)n_seeds : 0;
 	ctx->n_seeds = m;
-	if (!ctx->bot.has) {
+	if (!ctx->bot_ready) {
+		// first use.  An out-of-memory half way leaves the context as it was (what this attempt allocated is freed again and the
+		// next call tries anew) instead of half-initialised with kernels launched on null scratch pointers.
 		const size_t M = (size_t)ctx->cap_anchors, R = (size_t)ctx->cap_reads, NB = M / 1024 + 2;
 		chaindp::BottomScratch &s = ctx->bot;
-		HIP_TRY(ctx, bot_alloc(ctx, s.has, M));
-		HIP_TRY(ctx, bot_alloc(ctx, s.owner, M * 4)); HIP_TRY(ctx, bot_alloc(ctx, s.end_rec, M * 4)); HIP_TRY(ctx, bot_alloc(ctx, s.ccnt, M * 4));
-		HIP_TRY(ctx, bot_alloc(ctx, s.kpos, M * 4)); HIP_TRY(ctx, bot_alloc(ctx, s.bpos, M * 4));
-		HIP_TRY(ctx, bot_alloc(ctx, s.c_src, M * 4)); HIP_TRY(ctx, bot_alloc(ctx, s.c_dst, M * 4));
-		HIP_TRY(ctx, bot_alloc(ctx, s.key, M * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.skey, M * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.cu, M * 8));
-		HIP_TRY(ctx, bot_alloc(ctx, s.u_tmp, M * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.u_out, M * 8));
-		HIP_TRY(ctx, bot_alloc(ctx, s.b_tmp, M * 16)); HIP_TRY(ctx, bot_alloc(ctx, s.b_out, M * 16)); HIP_TRY(ctx, bot_alloc(ctx, s.w, M * 16));
-		HIP_TRY(ctx, bot_alloc(ctx, s.stacks, (M / 64 + 2 * R + 4) * 12));
-		HIP_TRY(ctx, bot_alloc(ctx, s.block_cnt, (NB > R + 2 ? NB : R + 2) * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.tile_tmp, (NB > R + 2 ? NB : R + 2) * 8));
-		HIP_TRY(ctx, bot_alloc(ctx, s.read_tot, (R + 2) * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.total, 8));
-		HIP_TRY(ctx, bot_alloc(ctx, s.ends_off, (R + 2) * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.chains_off, (R + 2) * 8)); HIP_TRY(ctx, bot_alloc(ctx, s.b_off, (R + 2) * 8));
+		const size_t first = ctx->bot_allocs.size();
+		hipError_t e = hipSuccess;
+#define BOT_ALLOC(field, bytes) if (e == hipSuccess) e = bot_alloc(ctx, s.field, (bytes))
+		BOT_ALLOC(has, M);
+		BOT_ALLOC(owner, M * 4); BOT_ALLOC(end_rec, M * 4); BOT_ALLOC(ccnt, M * 4); BOT_ALLOC(kpos, M * 4); BOT_ALLOC(bpos, M * 4);
+		BOT_ALLOC(c_src, M * 4); BOT_ALLOC(c_dst, M * 4);
+		BOT_ALLOC(key, M * 8); BOT_ALLOC(skey, M * 8); BOT_ALLOC(cu, M * 8); BOT_ALLOC(u_tmp, M * 8); BOT_ALLOC(u_out, M * 8);
+		BOT_ALLOC(b_tmp, M * 16); BOT_ALLOC(b_out, M * 16); BOT_ALLOC(w, M * 16);
+		BOT_ALLOC(stacks, (M / 64 + 2 * R + 4) * 12);
+		BOT_ALLOC(block_cnt, (NB > R + 2 ? NB : R + 2) * 8); BOT_ALLOC(tile_tmp, (NB > R + 2 ? NB : R + 2) * 8);
+		BOT_ALLOC(read_tot, (R + 2) * 8); BOT_ALLOC(total, 8);
+		BOT_ALLOC(ends_off, (R + 2) * 8); BOT_ALLOC(chains_off, (R + 2) * 8); BOT_ALLOC(b_off, (R + 2) * 8);
+#undef BOT_ALLOC
+		if (e != hipSuccess) {
+			for (size_t k = first; k < ctx->bot_allocs.size(); ++k) if (ctx->bot_allocs[k]) (void)hipFree(ctx->bot_allocs[k]);
+			ctx->bot_allocs.resize(first);
+			ctx->bot = chaindp::BottomScratch{};
+			ctx->err = std::string("backtrack buffers: ") + hipGetErrorString(e);
+			return CHAINDP_ERR_HIP;
+		}
+		ctx->bot_ready = true;
 	}
 	EventSet es; es.n = 0; es.slot0 = 3;
 	if (ctx->prof) {
@@ -838,15 +851,22 @@ extern "C" void chaindp_index_destroy(chaindp_index_t *ix)
 
 static int seed_reserve(chaindp_ctx *ctx, int64_t n_mini)
 {
-	if (!ctx->d_mini_off) {
+	if (!ctx->seed_ready) {
+		// first use: all or nothing, as in compact_launch
 		const size_t nr = (size_t)ctx->cap_reads;
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_mini_off, (nr + 1) * 8));
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_mp_off, (nr + 1) * 8));
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bid, (nr + 1) * 4));
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qlen, (nr + 1) * 4));
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->d_rep_len, (nr + 1) * 4));
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->seed.totals, 32));
-		HIP_TRY(ctx, hipMalloc((void**)&ctx->seed.stacks, ((size_t)ctx->cap_anchors / 64 + 2 * nr + 4) * 12));
+		void **slot[7] = {(void**)&ctx->d_mini_off, (void**)&ctx->d_mp_off, (void**)&ctx->d_bid, (void**)&ctx->d_qlen, (void**)&ctx->d_rep_len,
+		                  (void**)&ctx->seed.totals, (void**)&ctx->seed.stacks};
+		const size_t sz[7] = {(nr + 1) * 8, (nr + 1) * 8, (nr + 1) * 4, (nr + 1) * 4, (nr + 1) * 4, 32, ((size_t)ctx->cap_anchors / 64 + 2 * nr + 4) * 12};
+		void *nb[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+		hipError_t e = hipSuccess;
+		for (int k = 0; k < 7 && e == hipSuccess; ++k) e = hipMalloc(&nb[k], sz[k]);
+		if (e != hipSuccess) {
+			for (void *q : nb) if (q) (void)hipFree(q);
+			ctx->err = std::string("seed collection buffers: ") + hipGetErrorString(e);
+			return CHAINDP_ERR_HIP;
+		}
+		for (int k = 0; k < 7; ++k) *slot[k] = nb[k];
+		ctx->seed_ready = true;
 	}
 	if (n_mini > ctx->seed_cap_mini) {
 		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
