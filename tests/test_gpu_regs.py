@@ -90,6 +90,38 @@ def test_map_batch_minimizers_in_hits_out_equals_the_references_records(dev, pat
     assert np.array_equal(got["div"] < 0, unset) and np.allclose(got["div"][~unset], exp_div["div"][~unset], rtol=DIV_RTOL, atol=0)
 
 
+def test_map_batch_from_three_contexts_at_once(dev):
+    """What bench.py's map_batch.three_contexts measures and the packet shim's service contexts do: chaindp_map_batch from three host
+    threads, a context each, the index image shared -- every call returns the reference's records."""
+    import threading
+    path = REGS[-1]
+    k = np.load(path, allow_pickle=False)
+    g = np.load(os.path.join(os.path.dirname(os.path.dirname(path)), "seeds", os.path.basename(path)), allow_pickle=False)
+    pv = [int(x) for x in g["params"]]
+    par = P.ChainParams(max_dist_x=pv[0], max_dist_y=pv[1], bw=pv[2], max_skip=pv[3], min_sc=pv[4], is_cdna=pv[5], n_segs=1)
+    ix = dev.load_index([g["img_B"], g["img_H"], g["img_V"], g["img_P"]])
+    exp = k["regs"].view(ol.REG_DTYPE).reshape(-1).tobytes()
+    devs = [chaindp.Device(0, max_anchors=len(g["anchors"]) + 1024, max_reads=len(g["bid"]) + 1) for _ in range(3)]
+    bad = []
+
+    def work(d):
+        for _ in range(6):
+            roff, regs, rep_len, n_anchors = d.map_batch(ix, int(g["flag"]), int(g["mid_occ"]), par, int(k["min_cnt"]), g["mini_off"], g["mini"],
+                                                         g["bid"], g["qlen"], k["hash"])
+            if not (np.array_equal(roff, k["chains_off"]) and regs.tobytes() == exp and np.array_equal(rep_len, g["rep_len"])):
+                bad.append(1)
+    try:
+        th = [threading.Thread(target=work, args=(d,)) for d in devs]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    finally:
+        for d in devs:
+            d.close()
+    assert not bad
+
+
 @pytest.mark.parametrize("path", REGS, ids=[os.path.basename(p)[:-4] for p in REGS])
 def test_hits_match_the_committed_reference_records(dev, path):
     """From the fixture's anchors to the reference's own mm_gen_regs / mm_est_err records (tests/golden/regs/*.npz, made by
