@@ -37,8 +37,9 @@ struct chaindp_ctx {
 	unsigned long long *d_sumq = nullptr;
 	Unit *d_units = nullptr;
 	Unit *d_left = nullptr;               // units the two-per-wave kernel hands over to k_chain_units
-	unsigned long long *d_left_cnt = nullptr;   // [0] handed-over count | the twin kernel's queue << 32; [1] count of d_deep
+	unsigned long long *d_left_cnt = nullptr;   // [0] handed-over count | the twin kernel's queue << 32; [1] count of d_deep; [2] k_chain_dense1's two queues
 	Unit *d_deep = nullptr;               // units k_chain_units hands over to its k_chain_dense (scans that keep reaching past the ring)
+	int deep_route = 0;                   // test hook: 1 k_chain_dense, 2 k_chain_dense1 whatever the batch looks like
 	int deep_eager = 0;                   // test hook: hand over any unit with a few deep scans, whatever its length
 	bool deep_handover = true;            // CHAINDP_NO_DEEP_HANDOVER (diagnostic / A-B): every unit stays in the launch that took it
 	int variant = 0;                      // 0: k_chain_twin + k_chain_units for the rest; 1: k_chain_units, general variant; 2: k_chain_units only
@@ -170,7 +171,7 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_units, (na / 2 + 1) * sizeof(Unit));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 2 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left, (na / 2 + 1) * sizeof(Unit));
-	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left_cnt, 2 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left_cnt, 3 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_deep, (na / 128 + 2) * sizeof(Unit));   // a unit is handed over after 128 anchors at the earliest
 	size_t flags_bytes0 = 0, cblocks_bytes0 = 0;
 	chaindp::compact_scratch_bytes(ctx->cap_anchors, &flags_bytes0, &cblocks_bytes0);
@@ -260,7 +261,7 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		HIP_TRY(ctx, hipMemsetAsync(ctx->d_tg, 0, (size_t)ctx->cap_anchors * 8, st));
 		ctx->epoch = 1;
 	}
-	HIP_TRY(ctx, hipMemsetAsync(ctx->d_left_cnt, 0, 2 * sizeof(unsigned long long), st));
+	HIP_TRY(ctx, hipMemsetAsync(ctx->d_left_cnt, 0, 3 * sizeof(unsigned long long), st));
 	Unit *const deep = ctx->deep_handover ? ctx->d_deep : nullptr;
 	unsigned int *const deep_cnt = (unsigned int*)(ctx->d_left_cnt + 1);
 	if (ctx->variant == 0 && lut && d_n_segs == nullptr) {
@@ -272,15 +273,18 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		const int64_t left_grid = total / 2 < 32768 ? total / 2 : 32768;
 		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, left_grid, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_left,
 		                                   ctx->d_left_cnt, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
-		                                   ctx->d_units, ctx->d_counters, deep, deep_cnt, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_eager));
+		                                   ctx->d_units, ctx->d_counters, deep, deep_cnt, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_eager, ctx->deep_route));
 	} else
 		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, total / 2, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_units,
 		                                   ctx->d_counters, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
-		                                   nullptr, nullptr, deep, deep_cnt, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_eager));
+		                                   nullptr, nullptr, deep, deep_cnt, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_eager, ctx->deep_route));
 	// units whose scans kept reaching past the ring (dense repeats): redone by k_chain_dense
-	if (deep && lut)
+	if (deep && lut) {
 		HIP_TRY(ctx, chaindp::launch_chain_dense(st, q, total / 128 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,
-		                                         d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags));
+		                                         d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_route));
+		HIP_TRY(ctx, chaindp::launch_chain_dense1(st, q, total / 128 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,
+		                                          ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_route, (unsigned int*)(ctx->d_left_cnt + 2), d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags));
+	}
 	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[2], st)); ctx->pending.push_back(es); }
 	ctx->stats[2] = total; ctx->stats[3] = n_reads;
 	return CHAINDP_OK;
@@ -598,13 +602,15 @@ extern "C" int64_t chaindp_debug_leftover(chaindp_ctx_t *ctx)
 }
 
 // test hook (not in the public header): 0 keeps every unit in the launch that took it (the deep path of the small rings stays
-// covered by the parity tests), 1 (default) hands long units whose scans keep reaching past the ring to k_chain_dense, 2 any unit
-// with a few such scans (small test inputs reach k_chain_dense)
+// covered by the parity tests), 1 (default) hands long units whose scans keep reaching past the ring to k_chain_dense or, when the
+// batch is dense all over, k_chain_dense1; 2 any unit with a few such scans, to k_chain_dense; 3 the same to k_chain_dense1 (small
+// test inputs reach either kernel)
 extern "C" int chaindp_debug_set_deep_handover(chaindp_ctx_t *ctx, int on)
 {
 	if (!ctx) return CHAINDP_ERR_ARG;
 	ctx->deep_handover = on != 0;
-	ctx->deep_eager = on == 2;
+	ctx->deep_eager = on >= 2;
+	ctx->deep_route = on == 2 ? 1 : on == 3 ? 2 : 0;
 	return CHAINDP_OK;
 }
 

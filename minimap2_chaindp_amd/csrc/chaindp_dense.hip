@@ -75,6 +75,8 @@ struct DenseArgs {
 	int32_t *f, *p, *v;
 	int32_t *first_child;
 	uint8_t *flags;
+	const unsigned int *long_units;     // see dense_all(), chaindp_fast.h
+	int route;
 	unsigned long long *stamp;          // diagnostic build (-DCHAINDP_DENSE_STAMPS, run with CHAINDP_DENSE_STAMP=1): where wave 0's time goes
 };
 
@@ -373,10 +375,11 @@ __device__ __forceinline__ void run_unit_dense(const UnitCtx &c, int64_t room, i
 template <bool SAMEGAP>
 __global__ __launch_bounds__(64 * DN_WAVES) void k_chain_dense(DenseArgs g)
 {
+	if (dense_all(g.long_units, g.route)) return;                   // a batch that is dense all over: k_chain_dense1 has the units
 	UnitCtx c;
 	c.a = g.a; c.f = g.f; c.p = g.p; c.v = g.v; c.tg = nullptr; c.tg_hi = 0; c.first_child = g.first_child; c.flags = g.flags; c.min_sc = g.par.min_sc;
 	c.s_w = nullptr; c.s_t = nullptr; c.s_v = nullptr; c.s_xhi = nullptr; c.s_yhi = nullptr; c.s_lut = nullptr; c.s_dummy = nullptr;
-	c.deep_list = nullptr; c.deep_cnt = nullptr; c.deep_n = 0;
+	c.deep_list = nullptr; c.deep_cnt = nullptr; c.deep_cap = 0; c.deep_min = 0; c.deep_left = 0; c.deep_n = 0;
 	c.lane = threadIdx.x & 63;
 	c.maxx = (uint64_t)(int64_t)g.par.max_dist_x;
 	c.mdx = g.par.max_dist_x; c.mdy = g.par.max_dist_y; c.bw = g.par.bw; c.max_skip = g.par.max_skip; c.is_cdna = 0;
@@ -406,7 +409,8 @@ size_t dense_lds_bytes(int lut_stride) { return (size_t)DN_LUT + (size_t)lut_str
 
 hipError_t launch_chain_dense(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
                               const uint16_t *d_lut, int lut_stride, const Unit *d_deep, const unsigned long long *d_deep_cnt,
-                              int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags)
+                              int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags,
+                              const unsigned int *d_long_units, int deep_route)
 {
 	if (max_units <= 0 || !d_lut) return hipSuccess;
 	const size_t lds = dense_lds_bytes(lut_stride);
@@ -432,6 +436,7 @@ hipError_t launch_chain_dense(hipStream_t st, const Params &par, int64_t max_uni
 	DenseArgs g;
 	g.par = par; g.off = d_off; g.a = (const ulonglong2*)d_a; g.lut = d_lut; g.lut_stride = lut_stride;
 	g.units = d_deep; g.count = d_deep_cnt; g.f = d_f; g.p = d_p; g.v = d_v; g.first_child = d_first_child; g.flags = d_flags;
+	g.long_units = d_long_units; g.route = deep_route;
 	g.stamp = nullptr;
 #ifdef CHAINDP_DENSE_STAMPS
 	static unsigned long long *d_stamp = nullptr;

@@ -39,6 +39,7 @@ struct UnitCtx {
 	// scans of the current unit that went past the ring so far (nullptr: this launch keeps every unit)
 	Unit *deep_list;
 	unsigned int *deep_cnt;
+	unsigned int deep_cap;          // units handed over per batch at most
 	int deep_min, deep_left;        // CHAINDP_DEEP_HANDOVER, CHAINDP_DEEP_HANDOVER_LEFT (tests: 8, 0 -- any unit with a few deep scans)
 	mutable int deep_n;
 };
@@ -46,7 +47,16 @@ struct UnitCtx {
 // k_chain_units hands a table-driven unit to k_chain_dense once this many of its scans went past the ring, if that is at
 // least every second anchor so far and the unit may have this many anchors left: the unit starts over there, and a short unit
 // or one with the odd deep scan (ordinary ava-ont batches have a handful) would only become a tail of its own behind the launch
+// true: the batch is dense all over (k_chain_dense1 takes the handed-over units), false: it has a tail (k_chain_dense does).
+// route: 0 decides by the number of long units in the batch, 1 / 2 force the one or the other (tests)
+__device__ __forceinline__ bool dense_all(const unsigned int *long_units, int route)
+{
+	return route == 2 || (route == 0 && long_units && *long_units > CHAINDP_DENSE_MAX_LONG);
+}
+
+#ifndef CHAINDP_DEEP_HANDOVER
 #define CHAINDP_DEEP_HANDOVER 64
+#endif
 #define CHAINDP_DEEP_HANDOVER_LEFT 2048
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));

@@ -51,7 +51,8 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
                         int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags,
                         const Unit *d_units_all = nullptr, const unsigned long long *d_counters_all = nullptr,
                         Unit *d_deep = nullptr, unsigned int *d_deep_cnt = nullptr, const unsigned int *d_long_units = nullptr,
-                        int deep_eager = 0);   // tests: hand over any unit with a few deep scans
+                        int deep_eager = 0,    // tests: hand over any unit with a few deep scans
+                        int deep_route = 0);   // 0: the batch decides which dense kernel runs; 1: k_chain_dense; 2: k_chain_dense1 (tests)
 // *d_long_units: units of CHAINDP_LONG_UNIT anchors and more in the batch (PrepassScratch::hist + CHAINDP_LONG_UNIT_CLASS, valid
 // after launch_prepass); above CHAINDP_DENSE_MAX_LONG of them nothing is handed over
 #define CHAINDP_LONG_UNIT_CLASS 65      // hist[c] after k_unit_bases = units in length classes above c; class 65 ends at 8191 anchors
@@ -65,7 +66,14 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
 #define CHAINDP_DENSE_UNITS 2048u      // units handed over per batch (about two rounds of workgroups on the chip)
 hipError_t launch_chain_dense(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
                               const uint16_t *d_lut, int lut_stride, const Unit *d_deep, const unsigned long long *d_deep_cnt,
-                              int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags);
+                              int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags,
+                              const unsigned int *d_long_units, int deep_route);
+// ... or, when the batch is dense all over, by k_chain_dense1 (chaindp_dense1.hip): one wave per unit, many per CU, the same bit
+// marks, deep chunks four at a time.  Both are launched; the device decides which one has work (dense_all(), chaindp_fast.h).
+hipError_t launch_chain_dense1(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
+                               const uint16_t *d_lut, int lut_stride, const Unit *d_deep, const unsigned long long *d_deep_cnt,
+                               const unsigned int *d_long_units, int deep_route, unsigned int *d_queues,   // d_queues: two zeroed words
+                               int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags);
 
 // Two units per wave, 32 lanes each (chaindp_twin.hip): takes the ordinary units, appends the others (general-variant reads,
 // scans that reach beyond 64 predecessors) to d_left / *d_left_cnt (low 32 bits = count), which launch_chain then runs.

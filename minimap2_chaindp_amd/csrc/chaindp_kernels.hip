@@ -541,10 +541,8 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 		// A unit whose scans keep reaching past the ring (dense repeats: the window holds hundreds of predecessors and few of
 		// them are marked) spends its time in round trips to L2.  It is handed to k_chain_dense, which redoes it from scratch;
 		// what this wave has stored so far is what that kernel stores again.
-		// Only the first CHAINDP_DENSE_UNITS units to get here (units run longest first) are handed over: k_chain_dense shortens
-		// the batch's tail; a batch that is dense all over is bound by instruction count, and there eight waves per unit lose.
 		if (c.deep_list && c.deep_n >= c.deep_min && (2 * c.deep_n >= tile0 + 64 || c.deep_left == 0) && room - tile0 >= c.deep_left && tile0 + 64 < room && room <= CHAINDP_DENSE_BITCAP &&
-		    (unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c.deep_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < CHAINDP_DENSE_UNITS) {
+		    (unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c.deep_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < c.deep_cap) {
 			if (lane == 0) { Unit un; un.start = c.base; un.read = c.read; un.len = (int32_t)room; c.deep_list[atomicAdd(c.deep_cnt, 1u)] = un; }
 			return;
 		}
@@ -561,7 +559,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                     int32_t *f, int32_t *p, int32_t *v, unsigned long long *tg, uint32_t epoch,
                                                     int32_t *first_child, uint8_t *flags,
                                                     const Unit *__restrict__ units_all, const unsigned long long *__restrict__ counters_all,
-                                                    Unit *deep_list, unsigned int *deep_cnt, const unsigned int *__restrict__ long_units, int deep_eager)
+                                                    Unit *deep_list, unsigned int *deep_cnt, const unsigned int *__restrict__ long_units, int deep_eager, int deep_route)
 {
 	static_assert((RING & (RING - 1)) == 0 && RING >= 128, "RING must be a power of two >= 128");
 	extern __shared__ uint4 smem[];
@@ -578,10 +576,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 	c.lane = threadIdx.x;
 	// k_chain_dense keeps 32-bit differences over a ring of CHAINDP_DENSE_RING anchors: exact under the same condition as x32_ok below
 	c.deep_list = ((uint64_t)(int64_t)par.max_dist_x + 1) * (uint64_t)(CHAINDP_DENSE_RING + 1) < (1ull << 32) ? deep_list : nullptr;
-	// ... and it is for a batch's tail: with thousands of long units in the batch (*long_units: units of 8192 anchors and more,
-	// from the prepass' length classes) every SIMD is busy to the end anyway and the batch is bound by instruction count, where
-	// eight waves per unit lose (measured: 8000 dense units 0.24 G anchors/s here, 0.20 there)
-	if (long_units && *long_units > CHAINDP_DENSE_MAX_LONG) c.deep_list = nullptr;
+	// Which kernel takes them depends on the batch: with a few long units it has a tail, and k_chain_dense puts eight waves on each
+	// of the first CHAINDP_DENSE_UNITS handed over (units run longest first); with thousands of them (*long_units: units of 8192
+	// anchors and more, from the prepass' length classes) every SIMD is busy to the end, the batch is bound by what a pair evaluation
+	// costs, and k_chain_dense1 takes every unit that qualifies, one wave each
+	c.deep_cap = dense_all(long_units, deep_route) ? 0xffffffffu : CHAINDP_DENSE_UNITS;
 	c.deep_min = deep_eager ? 8 : CHAINDP_DEEP_HANDOVER; c.deep_left = deep_eager ? 0 : CHAINDP_DEEP_HANDOVER_LEFT;
 	c.deep_cnt = deep_cnt;
 	c.maxx = (uint64_t)(int64_t)par.max_dist_x;
@@ -636,7 +635,7 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
                         const Unit *d_units, const unsigned long long *d_counters,
                         int32_t *d_f, int32_t *d_p, int32_t *d_v, unsigned long long *d_tg, uint32_t epoch, int32_t *d_first_child, uint8_t *d_flags,
                         const Unit *d_units_all, const unsigned long long *d_counters_all, Unit *d_deep, unsigned int *d_deep_cnt,
-                        const unsigned int *d_long_units, int deep_eager)
+                        const unsigned int *d_long_units, int deep_eager, int deep_route)
 {
 	if (max_units <= 0) return hipSuccess;
 	// The number of units is only known on the device (counters[0]); the grid is sized for the upper
@@ -656,9 +655,9 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
 		if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
 	}
 	switch (ring) {
-	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt, d_long_units, deep_eager); break;
-	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt, d_long_units, deep_eager); break;
-	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt, d_long_units, deep_eager); break;
+	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt, d_long_units, deep_eager, deep_route); break;
+	case 512: hipLaunchKernelGGL(k_chain_units<512>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt, d_long_units, deep_eager, deep_route); break;
+	default:  hipLaunchKernelGGL(k_chain_units<256>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt, d_long_units, deep_eager, deep_route); break;
 	}
 	return hipGetLastError();
 }
