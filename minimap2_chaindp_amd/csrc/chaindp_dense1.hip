@@ -10,7 +10,7 @@
 //   * marks by distance as one bit each in LDS (derivation 11), sized for the units of the launch --
 //     a 32 K-anchor unit needs 4 KB -- so that a wave's LDS footprint stays small (ring of 128 anchors: 8.5 KB in all,
 //     18 waves per CU) and no mark ever goes to memory;
-//   * chunks in groups: the two ring chunks, then the deep chunks four at a time, are evaluated side by side -- loads in
+//   * chunks in groups: the two ring chunks, then the deep chunks two at a time, are evaluated side by side -- loads in
 //     flight together, one trip to L2 per group instead of two per chunk -- and only the walks over their lane masks
 //     (fast_walk) run one after the other.
 // It computes exactly what run_unit_fast of chaindp_kernels.hip computes (reference chain.c:246-284).  Which of the two dense
@@ -32,7 +32,12 @@ typedef FastLds<D1_RING> D1L;
 // lane without a mark ORs its zero, the read's table of 1 - cost (int16)
 #define D1_BM 3072u
 #define D1_RING_GROUP 2                 // = the ring
-#define D1_DEEP_GROUP 4                 // deep chunks evaluated per trip to L2
+#ifndef D1_WAVES_MAX
+#define D1_WAVES_MAX 6                  // waves per SIMD the register budget is cut for (LDS allows 4.5)
+#endif
+#ifndef D1_DEEP_GROUP
+#define D1_DEEP_GROUP 2                 // deep chunks evaluated per trip to L2 (8000 dense units: 1 -> 716 ms, 2 -> 551, 3 -> 602, 4 -> 600, 8 -> 679)
+#endif
 static_assert(D1L::V_OFF + 4u * D1_RING <= D1_BM && 64 * D1_RING_GROUP == D1_RING, "LDS layout");
 
 struct Dense1Args {
@@ -119,7 +124,7 @@ __device__ __forceinline__ bool d1_ring_group(const FastK &k, const Dense1Lds &l
 	return false;
 }
 
-// Four consecutive deep chunks (predecessors older than the ring: a, f, p come back from HBM/L2) of anchor i.  Only the window
+// D1_DEEP_GROUP consecutive deep chunks (predecessors older than the ring: a, f, p come back from HBM/L2) of anchor i.  Only the window
 // test is done in 64 bits (x_i - x_j of a predecessor this old may exceed 32 bits; for a lane inside the window it does not,
 // and every other difference is bounded by the window).  Returns true when the scan is complete.
 template <bool SAMEGAP>
@@ -230,7 +235,7 @@ __device__ __forceinline__ void run_unit_dense1(const UnitCtx &c, const Dense1Ld
 }
 
 template <bool SAMEGAP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 6))) void k_chain_dense1(Dense1Args g)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, D1_WAVES_MAX))) void k_chain_dense1(Dense1Args g)
 {
 	if (!dense_all(g.long_units, g.route)) return;                  // a batch with a tail: k_chain_dense has the units
 	UnitCtx c;

@@ -16,7 +16,7 @@ for n_reads in [int(x) for x in sys.argv[1:]] or [100]:
         dev.upload(off, a)
         cases = (("k_chain_units alone", 128, False), ("handover, as the batch decides", 128, True), ("handover to k_chain_dense", 128, 2), ("handover to k_chain_dense1", 128, 3))
         if os.environ.get("CHAINDP_LIB"):
-            cases = cases[1:3]
+            cases = cases[1:2]
         for label, ring, handover in cases:
             dev.set_ring(ring); dev.set_deep_handover(handover)
             dev.run_full(par); dev.sync()
