@@ -36,7 +36,8 @@ typedef FastLds<D1_RING> D1L;
 #define D1_WAVES_MAX 6                  // waves per SIMD the register budget is cut for (LDS allows 4.5)
 #endif
 #ifndef D1_DEEP_GROUP
-#define D1_DEEP_GROUP 2                 // deep chunks evaluated per trip to L2 (8000 dense units: 1 -> 716 ms, 2 -> 551, 3 -> 602, 4 -> 600, 8 -> 679)
+#define D1_DEEP_GROUP 2                 // deep chunks evaluated per trip to L2 (8000 dense units: 1 -> 716 ms, 2 -> 551, 3 -> 602, 4 -> 600, 8 -> 679;
+                                        // with the next group's loads requested a group ahead 590: the wave waits for LDS, not for L2)
 #endif
 static_assert(D1L::V_OFF + 4u * D1_RING <= D1_BM && 64 * D1_RING_GROUP == D1_RING, "LDS layout");
 
