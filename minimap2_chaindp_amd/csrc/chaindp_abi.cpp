@@ -172,7 +172,7 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 2 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left, (na / 2 + 1) * sizeof(Unit));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left_cnt, 3 * sizeof(unsigned long long));
-	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_deep, (na / 128 + 2) * sizeof(Unit));   // a unit is handed over after 128 anchors at the earliest
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_deep, (na / 64 + 2) * sizeof(Unit));    // a unit is handed over after its first 64-anchor tile at the earliest (test mode), with anchors to go
 	size_t flags_bytes0 = 0, cblocks_bytes0 = 0;
 	chaindp::compact_scratch_bytes(ctx->cap_anchors, &flags_bytes0, &cblocks_bytes0);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_first_child, na * 4);
@@ -280,9 +280,9 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		                                   nullptr, nullptr, deep, deep_cnt, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_eager, ctx->deep_route));
 	// units whose scans kept reaching past the ring (dense repeats): redone by k_chain_dense
 	if (deep && lut) {
-		HIP_TRY(ctx, chaindp::launch_chain_dense(st, q, total / 128 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,
+		HIP_TRY(ctx, chaindp::launch_chain_dense(st, q, total / 64 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,
 		                                         d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_route));
-		HIP_TRY(ctx, chaindp::launch_chain_dense1(st, q, total / 128 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,
+		HIP_TRY(ctx, chaindp::launch_chain_dense1(st, q, total / 64 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,
 		                                          ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_route, (unsigned int*)(ctx->d_left_cnt + 2), d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags));
 	}
 	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[2], st)); ctx->pending.push_back(es); }

@@ -149,7 +149,7 @@ __device__ __forceinline__ int unit_class(int32_t len)
 __global__ __launch_bounds__(256) void k_emit_units(int64_t n_reads, int64_t n_words, const int64_t *__restrict__ off,
                                                     const uint64_t *__restrict__ start_mask,
                                                     const unsigned long long *__restrict__ block_base, Unit *__restrict__ units,
-                                                    unsigned int *__restrict__ hist)
+                                                    unsigned int *__restrict__ hist, const int2 *__restrict__ block_reads)
 {
 	__shared__ unsigned int s_hist[UNIT_CLASSES];
 	if (threadIdx.x < UNIT_CLASSES) s_hist[threadIdx.x] = 0;
@@ -160,7 +160,10 @@ __global__ __launch_bounds__(256) void k_emit_units(int64_t n_reads, int64_t n_w
 		const int64_t b = w / PRE_WORDS;
 		uint64_t pos = (uint32_t)block_base[b];             // low word: units before this block
 		for (int64_t k = b * PRE_WORDS; k < w; ++k) pos += (uint64_t)__builtin_popcountll(start_mask[k]);
-		int64_t r = read_of(off, 0, n_reads - 1, w << 6);
+		// the read of the word's first anchor: from the block's read range (k_block_reads) instead of a search over all reads
+		// (fourteen dependent loads for 12 500 reads; a block usually lies in one read or straddles two)
+		const int2 rr = block_reads[b];
+		int64_t r = read_of(off, rr.x, rr.y, w << 6);
 		while (m) {
 			const int bit = __builtin_ctzll(m);
 			m &= m - 1;
@@ -267,7 +270,7 @@ hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, in
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, d_counters)) != hipSuccess) return e;
 	if ((e = hipMemsetAsync(sc.hist, 0, 2 * UNIT_CLASSES * sizeof(unsigned int), st)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_emit_units, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, n_reads, words, d_off,
-	                   sc.start_mask, sc.block_cnt, sc.units_tmp, sc.hist);
+	                   sc.start_mask, sc.block_cnt, sc.units_tmp, sc.hist, sc.block_reads);
 	hipLaunchKernelGGL(k_unit_bases, dim3(1), dim3(64), 0, st, sc.hist, sc.hist + UNIT_CLASSES);
 	hipLaunchKernelGGL(k_unit_scatter, dim3((unsigned)(blocks < 1024 ? (blocks > 0 ? blocks : 1) : 1024)), dim3(256), 0, st, d_counters, sc.units_tmp,
 	                   sc.hist, sc.hist + UNIT_CLASSES, d_units);
