@@ -221,6 +221,17 @@ struct TwinHot {
 #else
 #define TW_STAMP(...)
 #endif
+// two sets of stamps inside service(), one per build (-DCHAINDP_TWIN_STAMPS=1: flush and unit switch; =2: the rest): both do not fit
+#if defined(CHAINDP_TWIN_STAMPS) && CHAINDP_TWIN_STAMPS == 2
+#define TW_STAMP_A(...)
+#define TW_STAMP_B(...) __VA_ARGS__
+#elif defined(CHAINDP_TWIN_STAMPS)
+#define TW_STAMP_A(...) __VA_ARGS__
+#define TW_STAMP_B(...)
+#else
+#define TW_STAMP_A(...)
+#define TW_STAMP_B(...)
+#endif
 #define TW_NOW() __builtin_amdgcn_s_memtime()
 
 template <bool SAMEGAP>
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 	}
 	wave_mem_fence();
 
-	TW_STAMP(unsigned long long st_t0 = 0, st_service = 0, st_slow = 0, st_general = 0, st_n_service = 0, st_n_fast = 0, st_n_general = 0, st_flush = 0, st_unit = 0, st_n_unit = 0;)
+	TW_STAMP(unsigned long long st_t0 = 0; unsigned int st_service = 0, st_n_service = 0, st_n_fast = 0, st_flush = 0, st_unit = 0, st_n_unit = 0, st_head = 0, st_take = 0, st_tail = 0;)   // (32-bit sums: a wave's ticks fit, and the build has no registers to spare)
 	ulonglong2 an_nx = make_ulonglong2(0, 0);                      // this lane's anchor of its half's NEXT tile, requested a tile ahead
 
 	// One service round for the halves in `svc`, whose tile is exhausted (or which have no unit yet).  One half at a time, with
@@ -297,6 +308,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 		for (int hs = 0; hs < 2; ++hs) {
 			if (((svc >> (32 * hs)) & 1ull) == 0) continue;
 			if (h != hs) continue;
+			TW_STAMP_B(const unsigned long long th0 = g.stamp ? TW_NOW() : 0;)
 			const uint32_t sa = TW_ST + 64u * (uint32_t)hs;
 			const tw_u32x4 cw0 = tw_ld128(sa), cw1 = tw_ld128(sa + 16u);
 			const tw_u32x2 cw2 = tw_ld64(sa + 32u);
@@ -354,8 +366,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				c_tile0 += 32;
 				if (take_tile(an_nx) == 0) goes_on = false;                // it ended exactly on the boundary
 			}
+			TW_STAMP_B(if (g.stamp) st_take += (unsigned int)(TW_NOW() - th0);)
 			// ---- flush the finished tile
-			TW_STAMP(const unsigned long long tf0 = g.stamp ? TW_NOW() : 0;)
+			TW_STAMP_A(const unsigned long long tf0 = g.stamp ? TW_NOW() : 0;)
 			if (cnt_prev > 0) {
 				const int i_lane = tile_prev + hl;                           // this lane's anchor of the finished tile
 				const bool have = hl < cnt_prev;
@@ -401,9 +414,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 					g.flags[gi] = (uint8_t)((self ? 2 : 0) | maybe_first | (val >= g.par.min_sc ? 8 : 0) | (fi < val ? 16 : 0));
 				}
 			}
-			TW_STAMP(if (g.stamp) st_flush += TW_NOW() - tf0;)
-			TW_STAMP(const unsigned long long tu0 = g.stamp ? TW_NOW() : 0;)
-			TW_STAMP(if (g.stamp && !goes_on) ++st_n_unit;)
+			TW_STAMP_A(if (g.stamp) st_flush += (unsigned int)(TW_NOW() - tf0);)
+			TW_STAMP_A(const unsigned long long tu0 = g.stamp ? TW_NOW() : 0;)
+			TW_STAMP_A(if (g.stamp && !goes_on) ++st_n_unit;)
 			// ---- the unit is over: the half's next unit (units that are not for this kernel are handed over), its LDS, its first tile
 			while (!goes_on && live) {
 				Unit un;
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				u.slow = 0;
 				if (take_tile(an) > 0) goes_on = true;                         // (a unit has at least two anchors: always)
 			}
-			TW_STAMP(if (g.stamp) st_unit += TW_NOW() - tu0;)
+			TW_STAMP_A(if (g.stamp) st_unit += (unsigned int)(TW_NOW() - tu0);)
 			// ---- the tile's first anchor becomes current
 			if (live) {
 				const uint32_t i = (uint32_t)c_tile0;
@@ -566,15 +579,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 			}
 			if (!force_general && tile == 0) {
 				// a half wants its second chunk.  n_skip after the first: #B, as no A lane follows a B lane
-				TW_STAMP(const unsigned long long ts = g.stamp ? TW_NOW() : 0;)
 				svc = slow_tail(tw_smear_halves(X), a_cur + TW_PF, cB + (int)__builtin_amdgcn_inverse_ballot_w64(B));
-				TW_STAMP(if (g.stamp) st_slow += TW_NOW() - ts;)
 			}
 		} else {
 			// ------------------------------------------------------------ general pass: second chunks, idle halves, interleaved walks
 			force_general = false;
-			TW_STAMP(const unsigned long long tg0 = g.stamp ? TW_NOW() : 0;)
-			TW_STAMP(if (g.stamp) ++st_n_general;)
 			const uint32_t t0 = u.S - L16;
 			const tw_u32x2 xy = tw_ld64((t0 & 0x7f8u) + TW_XY);
 			const tw_u32x2 pf = tw_ld64((t0 & 0x3f8u) + TW_PF);
@@ -624,20 +633,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 			}
 			const uint64_t D = tw_smear_halves(brk | (OUT & TW_HI31) | ~live_m);   // idle halves count as done
 			svc = slow_tail(D, a_cur, nskip_after);
-			TW_STAMP(if (g.stamp) st_general += TW_NOW() - tg0;)
 		}
 		// ---------------------------------------------------------------- tile exhausted (or unit handed over): flush, next tile / unit
 		svc |= tw_smear_halves(TW_SGE(u.pc, u.pend) & live_m & ~contm);
 		if (__builtin_expect(svc != 0, 0)) {
 			TW_STAMP(const unsigned long long ts = g.stamp ? TW_NOW() : 0;)
 			service(svc & live_m);
-			TW_STAMP(if (g.stamp) { st_service += TW_NOW() - ts; ++st_n_service; })
+			TW_STAMP(if (g.stamp) { st_service += (unsigned int)(TW_NOW() - ts); ++st_n_service; })
 		}
 	}
 	TW_STAMP(if (g.stamp && lane == 0) {
-		unsigned long long *o = g.stamp + 8 * (size_t)blockIdx.x;
-		o[0] = TW_NOW() - st_t0; o[1] = st_service; o[2] = st_flush; o[3] = st_unit; o[4] = st_n_service; o[5] = st_n_fast; o[6] = st_n_unit; o[7] = 1;
-		(void)st_slow; (void)st_general; (void)st_n_general;
+		unsigned long long *o = g.stamp + 12 * (size_t)blockIdx.x;
+		o[0] = TW_NOW() - st_t0; o[1] = st_service; o[2] = st_flush; o[3] = st_unit; o[4] = st_n_service; o[5] = st_n_fast; o[6] = st_n_unit; o[7] = 1; o[8] = st_head; o[9] = st_take; o[10] = st_tail;
 	})
 #undef TW_COLD
 }
@@ -669,9 +676,9 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
 	// function print the averages -- it synchronises, so never set it in a timed run
 	static unsigned long long *d_stamp = nullptr;
 	const bool stamp = getenv("CHAINDP_TWIN_STAMP") != nullptr;
-	if (stamp && !d_stamp && hipMalloc((void**)&d_stamp, (size_t)cap * 64) != hipSuccess) d_stamp = nullptr;
+	if (stamp && !d_stamp && hipMalloc((void**)&d_stamp, (size_t)cap * 96) != hipSuccess) d_stamp = nullptr;
 	g.stamp = stamp ? d_stamp : nullptr;
-	if (g.stamp) (void)hipMemsetAsync(d_stamp, 0, (size_t)blocks * 64, st);
+	if (g.stamp) (void)hipMemsetAsync(d_stamp, 0, (size_t)blocks * 96, st);
 	{
 		hipFuncAttributes fa;                                        // LDS is addressed by raw byte offsets from 0: no static LDS may sit in front
 		const void *fn = par.max_dist_y >= par.max_dist_x ? (const void*)k_chain_twin<true> : (const void*)k_chain_twin<false>;
@@ -682,13 +689,17 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
 	if (par.max_dist_y >= par.max_dist_x) hipLaunchKernelGGL(k_chain_twin<true>, dim3((unsigned)blocks), dim3(64), TW_LDS_BYTES, st, g);
 	else hipLaunchKernelGGL(k_chain_twin<false>, dim3((unsigned)blocks), dim3(64), TW_LDS_BYTES, st, g);
 	if (g.stamp) {
-		std::vector<unsigned long long> hb((size_t)blocks * 8);
+		std::vector<unsigned long long> hb((size_t)blocks * 12);
 		if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hb.data(), d_stamp, hb.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-			double tot = 0, svc = 0, slow = 0, gen = 0, nsvc = 0, nfast = 0, ngen = 0, nb = 0;
-			for (int64_t b = 0; b < blocks; ++b) if (hb[(size_t)b * 8 + 7]) { tot += hb[b * 8]; svc += hb[b * 8 + 1]; slow += hb[b * 8 + 2]; gen += hb[b * 8 + 3]; nsvc += hb[b * 8 + 4]; nfast += hb[b * 8 + 5]; ngen += hb[b * 8 + 6]; ++nb; }
-			fprintf(stderr, "[twin stamp] %.0f waves, %.0f ticks each: service %.1f%% (%.0f calls, %.0f ticks each), of it flush %.1f%%, unit switch %.1f%% (%.0f switches, %.0f ticks each), "
-			                "passes %.0f (%.0f ticks each, everything else included)\n", nb, tot / nb, 100.0 * svc / tot, nsvc, svc / (nsvc > 0 ? nsvc : 1),
-			        100.0 * slow / tot, 100.0 * gen / tot, ngen, gen / (ngen > 0 ? ngen : 1), nfast, (tot - svc) / (nfast > 0 ? nfast : 1));
+			double tot = 0, svc = 0, flush = 0, unit = 0, nsvc = 0, nfast = 0, nunit = 0, nb = 0, head = 0, take = 0, tail = 0;
+			for (int64_t b = 0; b < blocks; ++b) if (hb[(size_t)b * 12 + 7]) {
+				const unsigned long long *o = &hb[(size_t)b * 12];
+				tot += o[0]; svc += o[1]; flush += o[2]; unit += o[3]; nsvc += o[4]; nfast += o[5]; nunit += o[6]; head += o[8]; take += o[9]; tail += o[10]; ++nb;
+			}
+			fprintf(stderr, "[twin stamp] %.0f waves, %.0f ticks each: service %.1f%% (%.0f calls, %.0f ticks each: cold state and decisions %.0f, next tile %.0f, flush %.0f, "
+			                "unit switch %.0f (%.0f switches, %.0f ticks each), first anchor and cold state back %.0f), passes %.0f (%.0f ticks each, everything else included)\n",
+			        nb, tot / nb, 100.0 * svc / tot, nsvc, svc / (nsvc > 0 ? nsvc : 1), head / (nsvc > 0 ? nsvc : 1), take / (nsvc > 0 ? nsvc : 1), flush / (nsvc > 0 ? nsvc : 1),
+			        unit / (nsvc > 0 ? nsvc : 1), nunit, unit / (nunit > 0 ? nunit : 1), tail / (nsvc > 0 ? nsvc : 1), nfast, (tot - svc) / (nfast > 0 ? nfast : 1));
 		}
 	}
 	return hipGetLastError();
