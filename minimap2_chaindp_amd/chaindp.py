@@ -4,6 +4,7 @@ Thin by design: numpy arrays in, numpy arrays out, every call goes through the C
 kernels.  There is NO CPU implementation behind this module: a missing library or a missing GPU
 raises.  Per read the results equal the reference's mm_chain_dp_fpga (chain.c:218-327).
 """
+import collections
 import ctypes as C
 import os
 
@@ -379,7 +380,7 @@ class Pipe:
         if not self._p:
             raise ChainDPError((self._lib.chaindp_pipe_last_error(None) or b"").decode())
         self.depth = depth
-        self._keep = {}
+        self._keep = collections.deque()       # host arrays of the batches in flight, oldest first (batches complete in submission order)
 
     def close(self):
         if self._p:
@@ -403,7 +404,7 @@ class Pipe:
         if rc == -5:
             return False
         self._check(rc)
-        self._keep[tag] = (off, anchors, ns)
+        self._keep.append((off, anchors, ns))   # by submission, not by tag: two batches may carry the same tag
         return True
 
     def wait(self, copy=True):
@@ -415,7 +416,8 @@ class Pipe:
         seeds = np.ctypeslib.as_array((C.c_uint8 * max(r.n_seeds * 24, 1)).from_address(r.seeds))[:r.n_seeds * 24].view(SEED_DTYPE)
         if copy:
             soff, seeds = soff.copy(), seeds.copy()
-        self._keep.pop(r.tag, None)
+        if self._keep:
+            self._keep.popleft()
         return r.tag, soff, seeds
 
     def release(self):

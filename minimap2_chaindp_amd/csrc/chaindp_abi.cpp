@@ -42,6 +42,7 @@ struct chaindp_ctx {
 	int deep_route = 0;                   // test hook: 1 k_chain_dense, 2 k_chain_dense1 whatever the batch looks like
 	int deep_eager = 0;                   // test hook: hand over any unit with a few deep scans, whatever its length
 	bool deep_handover = true;            // CHAINDP_NO_DEEP_HANDOVER (diagnostic / A-B): every unit stays in the launch that took it
+	bool twin_force_left = false;         // CHAINDP_TWIN_FORCE_LEFT (tests): k_chain_twin hands every unit over; read once, at chaindp_create
 	int variant = 0;                      // 0: k_chain_twin + k_chain_units for the rest; 1: k_chain_units, general variant; 2: k_chain_units only
 	unsigned long long *d_counters = nullptr;
 	chaindp::PrepassScratch pre = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -186,7 +187,8 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.hist, 2 * 128 * sizeof(unsigned int));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.block_reads, blocks_bytes);   // 8 B per block, like the counters
 	ctx->cmp.block_reads = ctx->pre.block_reads;
-	ctx->deep_handover = getenv("CHAINDP_NO_DEEP_HANDOVER") == nullptr;
+	ctx->deep_handover = getenv("CHAINDP_NO_DEEP_HANDOVER") == nullptr;      // diagnostic switches are read here, once per context:
+	ctx->twin_force_left = getenv("CHAINDP_TWIN_FORCE_LEFT") != nullptr;     // never on the launch path (contexts run from several host threads)
 	if (e != hipSuccess) {
 		g_create_error = std::string("chaindp_create: ") + hipGetErrorString(e);
 		chaindp_destroy(ctx);
@@ -269,7 +271,7 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		if (total > 0) HIP_TRY(ctx, hipMemsetAsync(ctx->d_first_child, 0x7f, (size_t)total * 4, st));   // NO_CHILD everywhere (chaindp_wave.h)
 		HIP_TRY(ctx, chaindp::launch_chain_twin(st, q, total / 2, d_off, d_a, ctx->d_sumq, lut, lut_stride, ctx->d_units, ctx->d_counters,
 		                                        d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->d_left, (unsigned int*)ctx->d_left_cnt,
-		                                        getenv("CHAINDP_TWIN_FORCE_LEFT") != nullptr, total));
+		                                        ctx->twin_force_left ? 1 : 0, total));
 		const int64_t left_grid = total / 2 < 32768 ? total / 2 : 32768;
 		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, left_grid, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_left,
 		                                   ctx->d_left_cnt, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
@@ -591,14 +593,17 @@ extern "C" int chaindp_est_err(chaindp_ctx_t *ctx, const int64_t *regs_off, chai
 	return CHAINDP_OK;
 }
 
-// test hook (not in the public header): units the two-per-wave kernel handed over to k_chain_units in the last run
+// test hook (not in the public header): units the two-per-wave kernel handed over to k_chain_units in the last run.  When that
+// kernel declines the whole batch (long units: map-ont, dense repeats) the word on the device is the marker 0xffffffff, "every
+// unit": reported as the batch's unit count
 extern "C" int64_t chaindp_debug_leftover(chaindp_ctx_t *ctx)
 {
 	if (!ctx || !ctx->d_left_cnt) return -1;
-	unsigned long long c = 0;
+	unsigned long long c = 0, cnt = 0;
 	if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
-	    hipMemcpy(&c, ctx->d_left_cnt, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-	return (int64_t)(uint32_t)c;
+	    hipMemcpy(&c, ctx->d_left_cnt, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess ||
+	    hipMemcpy(&cnt, ctx->d_counters, sizeof(cnt), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	return (uint32_t)c == 0xffffffffu ? (int64_t)(uint32_t)cnt : (int64_t)(uint32_t)c;
 }
 
 // test hook (not in the public header): 0 keeps every unit in the launch that took it (the deep path of the small rings stays

@@ -390,7 +390,8 @@ hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, in
 	const dim3 gw((unsigned)((blocks + CMP_BLOCK / 64 - 1) / (CMP_BLOCK / 64)));    // one wave per 1024-anchor block
 	hipLaunchKernelGGL(k_count, gw, b, 0, st, n_reads, total, d_off, d_p, d_first_child, sc.flags, sc.block_cnt, sc.block_reads, sc.sub);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, sc.n_seeds)) != hipSuccess) return e;
-	if (getenv("CHAINDP_COMPACT_TWO_PASS")) {                          // the earlier form (positions to id[], then records), kept for A/B runs
+	static const bool two_pass = getenv("CHAINDP_COMPACT_TWO_PASS") != nullptr;   // (read once: not on the launch path)
+	if (two_pass) {                          // the earlier form (positions to id[], then records), kept for A/B runs
 		hipLaunchKernelGGL(k_positions, gw, b, 0, st, n_reads, total, d_off, d_p, sc.flags, sc.block_cnt, d_id, d_seeds_off, sc.block_reads);
 		hipLaunchKernelGGL(k_finish_offsets, dim3(1), dim3(1), 0, st, n_reads, total, d_off, sc.n_seeds, d_seeds_off);
 		hipLaunchKernelGGL(k_write_seeds, g, b, 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a, d_f, d_p, d_v, sc.flags, d_id,

@@ -424,10 +424,8 @@ hipError_t launch_chain_dense(hipStream_t st, const Params &par, int64_t max_uni
 	if (blocks > max_units) blocks = max_units;
 	const void *fn = par.max_dist_y >= par.max_dist_x ? (const void*)k_chain_dense<true> : (const void*)k_chain_dense<false>;
 	{
-		hipFuncAttributes fa;                                        // LDS is addressed by raw byte offsets from 0: no static LDS may sit in front
-		const hipError_t e = hipFuncGetAttributes(&fa, fn);
+		const hipError_t e = check_no_static_lds(fn);        // LDS is addressed by raw byte offsets from 0
 		if (e != hipSuccess) return e;
-		if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
 	}
 	if (lds > 64 * 1024) {
 		const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -440,7 +438,7 @@ hipError_t launch_chain_dense(hipStream_t st, const Params &par, int64_t max_uni
 	g.stamp = nullptr;
 #ifdef CHAINDP_DENSE_STAMPS
 	static unsigned long long *d_stamp = nullptr;
-	const bool stamp = getenv("CHAINDP_DENSE_STAMP") != nullptr;
+	static const bool stamp = getenv("CHAINDP_DENSE_STAMP") != nullptr;
 	if (stamp && !d_stamp && hipMalloc((void**)&d_stamp, 16 * 8) != hipSuccess) d_stamp = nullptr;
 	if (stamp && d_stamp) { (void)hipMemsetAsync(d_stamp, 0, 16 * 8, st); g.stamp = d_stamp; }
 #endif

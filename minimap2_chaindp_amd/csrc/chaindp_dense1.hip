@@ -287,10 +287,8 @@ hipError_t launch_chain_dense1(hipStream_t st, const Params &par, int64_t max_un
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 	const void *fn = par.max_dist_y >= par.max_dist_x ? (const void*)k_chain_dense1<true> : (const void*)k_chain_dense1<false>;
 	{
-		hipFuncAttributes fa;                                        // LDS is addressed by raw byte offsets from 0: no static LDS may sit in front
-		const hipError_t e = hipFuncGetAttributes(&fa, fn);
+		const hipError_t e = check_no_static_lds(fn);        // LDS is addressed by raw byte offsets from 0
 		if (e != hipSuccess) return e;
-		if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
 	}
 	Dense1Args g;
 	g.par = par; g.off = d_off; g.a = (const ulonglong2*)d_a; g.lut = d_lut; g.lut_stride = lut_stride;

@@ -163,5 +163,9 @@ hipError_t launch_scatter_seeds(hipStream_t st, int64_t n_reads, const int64_t *
 hipError_t launch_copy_out(hipStream_t st, void *h_dst, const void *d_src, size_t bytes, int blocks);
 hipError_t launch_scatter_words(hipStream_t st, int64_t n_reads, const int64_t *d_woff, void *const *d_dst, const void *d_words);
 
+// The DP kernels address LDS by raw byte offsets from 0, so none of them may have static LDS in front of its dynamic segment.
+// Checked once per kernel (the answer is a property of the code object), not once per launch.
+hipError_t check_no_static_lds(const void *fn);
+
 } // namespace chaindp
 #endif

@@ -21,6 +21,9 @@
 //                   predecessors older than the ring are read back from HBM/L2 (the "deep" path).
 //   Integer arithmetic only, except the reference's own f32 divide and (int)(dd * .01 * avg_qspan) in f64.
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include <stdint.h>
 #include <limits.h>
 #include "chaindp_kernels.h"
@@ -626,6 +629,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
 // ---------------------------------------------------------------- launchers
 
+hipError_t check_no_static_lds(const void *fn)
+{
+	static std::mutex mu;
+	static std::vector<std::pair<const void*, hipError_t>> seen;
+	std::lock_guard<std::mutex> lk(mu);
+	for (const auto &kv : seen) if (kv.first == fn) return kv.second;
+	hipFuncAttributes fa;
+	hipError_t e = hipFuncGetAttributes(&fa, fn);
+	if (e != hipSuccess) return e;                                 // (not cached: a failed query is tried again)
+	e = fa.sharedSizeBytes != 0 ? hipErrorInvalidConfiguration : hipSuccess;
+	seen.emplace_back(fn, e);
+	return e;
+}
+
 size_t chain_lds_bytes(int ring, int lut_stride)
 {
 	return (size_t)ring * 32 + 16 + (size_t)lut_stride * 2;
@@ -646,13 +663,9 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
 	const ulonglong2 *aa = (const ulonglong2*)d_a;
 	const size_t lds = chain_lds_bytes(ring, d_lut ? lut_stride : 0);
 	{
-		// the fast variant addresses LDS by raw byte offsets from 0: the kernel must have no static LDS in front of
-		// its dynamic segment
-		hipFuncAttributes fa;
 		const void *fn = ring == 128 ? (const void*)k_chain_units<128> : ring == 512 ? (const void*)k_chain_units<512> : (const void*)k_chain_units<256>;
-		const hipError_t e = hipFuncGetAttributes(&fa, fn);
+		const hipError_t e = check_no_static_lds(fn);        // LDS is addressed by raw byte offsets from 0
 		if (e != hipSuccess) return e;
-		if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
 	}
 	switch (ring) {
 	case 128: hipLaunchKernelGGL(k_chain_units<128>, dim3((unsigned)blocks), dim3(64), lds, st, par, d_off, aa, d_n_segs, d_sumq, d_lut, lut_stride, d_units, d_counters, d_f, d_p, d_v, d_tg, epoch, d_first_child, d_flags, d_units_all, d_counters_all, d_deep, d_deep_cnt, d_long_units, deep_eager, deep_route); break;

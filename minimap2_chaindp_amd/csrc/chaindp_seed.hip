@@ -764,7 +764,7 @@ hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag
 		}
 		const int64_t units = n_reads + (total > cap && cap > 0 ? total / 65 : 0);
 		const unsigned grid = (unsigned)(units < 256 * 8 ? units : 256 * 8);
-		const int try_network = getenv("CHAINDP_SEED_FORCE_EXACT") == nullptr;      // measurement switch: every read through the reference's procedure
+		static const int try_network = getenv("CHAINDP_SEED_FORCE_EXACT") == nullptr;      // measurement switch: every read through the reference's procedure
 		if (cap > 0) {
 			size_t lds = seed_sort_lds_bytes(max_n, 32, 8);
 			if (max_n2 > max_n && seed_sort_lds_bytes(max_n2, 4, 2) > lds) lds = seed_sort_lds_bytes(max_n2, 4, 2);

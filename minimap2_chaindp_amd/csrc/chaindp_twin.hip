@@ -45,6 +45,21 @@ namespace chaindp {
 #define TW_LUT_HALF 512u
 #define TW_ST 6176u
 #define TW_LDS_BYTES 6304u
+// ring addressing.  TW_EXP_DEINT: XY as [half][128] 8 B and PF as [half][64] 8 B (a half's 32 lanes read 256 contiguous bytes:
+// no bank conflict inside the lane group) instead of [slot][half]
+#ifdef TW_EXP_DEINT
+#define TW_SH 3
+#define TW_XYA(t) ((((t)) & 0x3f8u) | c_xyb)
+#define TW_PFA(t) ((((t)) & 0x1f8u) | c_pfb)
+#define TW_XYS(slot, hh) (((uint32_t)(slot) << 3) + TW_XY + 1024u * (uint32_t)(hh))
+#define TW_PFS(slot, hh) (((uint32_t)(slot) << 3) + TW_PF + 512u * (uint32_t)(hh))
+#else
+#define TW_SH 4
+#define TW_XYA(t) ((((t)) & 0x7f8u) + TW_XY)
+#define TW_PFA(t) ((((t)) & 0x3f8u) + TW_PF)
+#define TW_XYS(slot, hh) (((uint32_t)(slot) << 4 | (uint32_t)(hh) << 3) + TW_XY)
+#define TW_PFS(slot, hh) (((uint32_t)(slot) << 4 | (uint32_t)(hh) << 3) + TW_PF)
+#endif
 #define TW_RING 64                      // predecessors a scan can reach in this kernel (two chunks of 32)
 #define TW_QCH 8                        // units a half takes from the queue at a time
 
@@ -243,14 +258,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 	const uint64_t my_half = hi_half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
 
 	// ---- per-lane constants (vector registers on purpose, see TW_VREG)
-	uint32_t L16 = (uint32_t)hl << 4;
+	uint32_t L16 = (uint32_t)hl << TW_SH;
 	const uint32_t mkbase = TW_MK + TW_MK_HALF * (uint32_t)h;      // this half's mark words
 	const uint32_t curbase = TW_CUR + TW_CUR_HALF * (uint32_t)h;   // this half's CUR entries
 	uint32_t c_mkbase = mkbase;
 	uint32_t c_far = mkbase + 256u;                                // its sink word
 	uint32_t c_own = mkbase + ((uint32_t)hl << 2);                 // lane's own mark word in chunk 0
 	uint32_t c_lut = TW_LUT + TW_LUT_HALF * (uint32_t)h;
+#ifdef TW_EXP_DEINT
+	uint32_t c_8h = 0u;
+	uint32_t c_xyb = TW_XY + 1024u * (uint32_t)h, c_pfb = TW_PF + 512u * (uint32_t)h;
+	TW_VREG(c_xyb); TW_VREG(c_pfb);
+#else
 	uint32_t c_8h = (uint32_t)h << 3;
+#endif
 	uint32_t c_M = (uint32_t)g.par.max_dist_x;
 	uint32_t c_bw = (uint32_t)g.par.bw;
 	uint32_t c_cbw = c_M - 1u > c_bw ? c_M - 1u - c_bw : 0u;
@@ -344,7 +365,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				wave_mem_fence();
 				if (hl < cnt) {
 					const int sp = span_of_hi((uint32_t)(an.y >> 32));
-					tw_st64((((uint32_t)i_lane & 127u) << 4 | c_8h) + TW_XY, (uint32_t)an.x + 1u, (uint32_t)an.y + 1u);
+					tw_st64(TW_XYS((uint32_t)i_lane & 127u, hs), (uint32_t)an.x + 1u, (uint32_t)an.y + 1u);
 					tw_st128(curbase + ((uint32_t)hl << 4), (uint32_t)an.x, (uint32_t)an.y, (uint32_t)(sp - 1), (uint32_t)sp);
 				}
 				wave_mem_fence();
@@ -375,7 +396,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				const int64_t gi = base_prev + i_lane;
 				int fi = 0, p4 = -4;
 				if (have) {
-					const tw_u32x2 pf = tw_ld64((((uint32_t)i_lane & 63u) << 4 | c_8h) + TW_PF);
+					const tw_u32x2 pf = tw_ld64(TW_PFS((uint32_t)i_lane & 63u, hs));
 					p4 = (int)pf.x; fi = (int)pf.y;
 				}
 				const int pi = p4 >> 2;                                      // unit-relative predecessor, -1 = none
@@ -450,7 +471,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 					tw_st32(c_lut + ((uint32_t)k << 2), (int)w);
 				}
 				const uint32_t x_none = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)an.x, 32 * hs) - (uint32_t)maxx - 1u;   // "no anchor here" (x+1 encoding)
-				for (int k = hl; k < 128; k += 32) tw_st64(((uint32_t)k << 4 | c_8h) + TW_XY, x_none, 0u);
+				for (int k = hl; k < 128; k += 32) tw_st64(TW_XYS(k, hs), x_none, 0u);
 				for (int k = hl; k < 65; k += 32) tw_st32(mkbase + ((uint32_t)k << 2), -1);
 				wave_mem_fence();
 				c_xcarry = 0;
@@ -462,7 +483,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 			if (live) {
 				const uint32_t i = (uint32_t)c_tile0;
 				u.maxj4 = -4; u.nskip = 0; u.kb4 = 0;
-				u.S = (i - 1u) << 4 | c_8h; u.m4 = ((i - 1u) << 2) + mkbase;
+				u.S = (i - 1u) << TW_SH | c_8h; u.m4 = ((i - 1u) << 2) + mkbase;
 			} else lane_retired = true;
 			if (hl == 0) {
 				tw_st128(sa, (uint32_t)c_next, (uint32_t)((uint64_t)c_next >> 32), (uint32_t)c_base, (uint32_t)((uint64_t)c_base >> 32));
@@ -488,11 +509,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 		if (__builtin_amdgcn_inverse_ballot_w64(D)) {
 			u.maxj4 = -4; u.nskip = 0;
 			u.m4 += 4u;
-			u.S = ((u.m4 - c_mkbase) << 2) | c_8h; u.kb4 = 0;
+			u.S = ((u.m4 - c_mkbase) << (TW_SH - 2)) | c_8h; u.kb4 = 0;
 			u.pc += 16u;
 		} else {
 			u.nskip = vlast; u.maxj4 = (int)cur.x; u.maxf = (int)cur.y;
-			u.S -= 512u; u.kb4 = 128u;
+			u.S -= 32u << TW_SH; u.kb4 = 128u;
 			++u.slow;
 		}
 		contm = ~D & ~giveup & live_m;
@@ -528,8 +549,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 			uint32_t a_cur;
 			for (;;) {
 				const uint32_t t0 = u.S - L16;                               // lane k <-> predecessor j = jtop - k of its half's anchor
-				const tw_u32x2 xy = tw_ld64((t0 & 0x7f8u) + TW_XY);
-				const tw_u32x2 pf = tw_ld64((t0 & 0x3f8u) + TW_PF);
+				const tw_u32x2 xy = tw_ld64(TW_XYA(t0));
+				const tw_u32x2 pf = tw_ld64(TW_PFA(t0));
 				const tw_u32x4 cur = tw_ld128(u.pc);                         // the anchor itself: x, q, q_span - 1, q_span
 				const uint32_t drm1 = cur.x - xy.x, dqm1 = cur.y - xy.y;     // the ring holds x + 1, q + 1: differences minus one
 				const uint32_t ddl = tw_sad(drm1, dqm1, c_lut);              // |dr - dq| + the half's table base
@@ -538,11 +559,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				const uint64_t okm = TW_ULT(m3, c_M);                        // chain.c:252-260 as one compare
 				// the mark round trip (chain.c:281: store by distance, the others to the sink; then the lane's own word) and the table
 				// lookup are issued back to back, before anything waits for either
+#ifdef TW_EXP_EXECMARK
+				if (__builtin_amdgcn_inverse_ballot_w64(okm)) tw_st32(min(u.m4 - pf.x, c_far), (int)u.m4);
+#else
 				const uint32_t dst = TW_SEL(okm, min(u.m4 - pf.x, c_far), c_far);
 				tw_st32(dst, (int)u.m4);
+#endif
 				wave_mem_fence();
 				const int tj = tw_ld32(c_own);
+#ifdef TW_EXP_NOCLAMP
+				const int lutv = tw_ld_i8(ddl);                              // lanes that fail the filters read anything (out of range: 0); masked below
+#else
 				const int lutv = tw_ld_i8(min(ddl, c_bwl));
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 				__builtin_amdgcn_sched_barrier(0);
 #endif
@@ -560,8 +589,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				if (__builtin_expect((TW_SGT(cB, 0) & A) != 0, 0)) { force_general = true; break; }
 				// the running max goes to PF[i]: the half's last A lane writes its own score and predecessor, or (none) the half's
 				// lane 0 writes "no predecessor, q_span"
-				const uint32_t S1 = u.S + 16u;
-				a_cur = S1 & 0x3f8u;                                         // PF slot of anchor i (S = 16 (i - 1) + 8h in the first chunk)
+				const uint32_t S1 = u.S + (1u << TW_SH);
+				a_cur = TW_PFA(S1) - TW_PF;                                  // PF slot of anchor i (S = 16 (i - 1) + 8h in the first chunk)
 				{
 					const uint32_t wp = TW_SEL(A, u.m4 - c_own, 0xfffffffcu);      // 4 j of the lane's predecessor: 4 (i - 1 - k)
 					const int wf = TW_SEL(A, sc, (int)cur.w);
@@ -585,8 +614,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 			// ------------------------------------------------------------ general pass: second chunks, idle halves, interleaved walks
 			force_general = false;
 			const uint32_t t0 = u.S - L16;
-			const tw_u32x2 xy = tw_ld64((t0 & 0x7f8u) + TW_XY);
-			const tw_u32x2 pf = tw_ld64((t0 & 0x3f8u) + TW_PF);
+			const tw_u32x2 xy = tw_ld64(TW_XYA(t0));
+			const tw_u32x2 pf = tw_ld64(TW_PFA(t0));
 			const tw_u32x4 cur = tw_ld128(u.pc);
 			const uint64_t first = ~contm;                                       // halves in their first chunk: running max = q_span, nothing carried
 			const int maxf = TW_SEL(first, (int)cur.w, u.maxf);
@@ -625,7 +654,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				brk = TW_SGT(nskip_after, c_ms) & B;
 				Ap = tw_below_first(A, brk);
 			}
-			const uint32_t a_cur = (((((u.m4 - c_mkbase) + 4u) << 2) & 0x3f8u) | c_8h) + TW_PF;   // PF slot of anchor i (m4 = 4 (i - 1) + mark base)
+			const uint32_t a_cur = TW_PFA((((u.m4 - c_mkbase) + 4u) << (TW_SH - 2)) | c_8h);   // PF slot of anchor i (m4 = 4 (i - 1) + mark base)
 			{
 				const uint32_t wp = TW_SEL(Ap, u.m4 - c_own - u.kb4, maxj4);          // 4 j = 4 (i - 1 - 32 c - k)
 				const int wf = TW_SEL(Ap, sc, maxf);
@@ -675,16 +704,14 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
 	// diagnostic: CHAINDP_TWIN_STAMP=1 makes the kernel stamp where its waves' time goes (s_memtime: shader-clock ticks) and this
 	// function print the averages -- it synchronises, so never set it in a timed run
 	static unsigned long long *d_stamp = nullptr;
-	const bool stamp = getenv("CHAINDP_TWIN_STAMP") != nullptr;
+	static const bool stamp = getenv("CHAINDP_TWIN_STAMP") != nullptr;           // (read once: not on the launch path)
 	if (stamp && !d_stamp && hipMalloc((void**)&d_stamp, (size_t)cap * 96) != hipSuccess) d_stamp = nullptr;
 	g.stamp = stamp ? d_stamp : nullptr;
 	if (g.stamp) (void)hipMemsetAsync(d_stamp, 0, (size_t)blocks * 96, st);
 	{
-		hipFuncAttributes fa;                                        // LDS is addressed by raw byte offsets from 0: no static LDS may sit in front
 		const void *fn = par.max_dist_y >= par.max_dist_x ? (const void*)k_chain_twin<true> : (const void*)k_chain_twin<false>;
-		const hipError_t e = hipFuncGetAttributes(&fa, fn);
+		const hipError_t e = check_no_static_lds(fn);        // LDS is addressed by raw byte offsets from 0
 		if (e != hipSuccess) return e;
-		if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
 	}
 	if (par.max_dist_y >= par.max_dist_x) hipLaunchKernelGGL(k_chain_twin<true>, dim3((unsigned)blocks), dim3(64), TW_LDS_BYTES, st, g);
 	else hipLaunchKernelGGL(k_chain_twin<false>, dim3((unsigned)blocks), dim3(64), TW_LDS_BYTES, st, g);

@@ -105,11 +105,21 @@ private:
 	std::vector<uint8_t> blob_[4];
 };
 
+// A device copy of one sealed index image.  Held by reference count: every batch keeps its copy alive until its kernels are
+// done, so an image that is replaced in mid-stream is freed by the last batch that looked seeds up in it, never under one.
+struct DevIndex {
+	chaindp_index_t *idx;
+	explicit DevIndex(chaindp_index_t *i) : idx(i) {}
+	~DevIndex() { if (idx) chaindp_index_destroy(idx); }
+	DevIndex(const DevIndex&) = delete;
+	DevIndex &operator=(const DevIndex&) = delete;
+};
+
 // what the service contexts of one GPU share: the device copy of the index image (one per GPU, not one per context)
 struct GpuShare {
 	std::mutex mu;                      // serialises the (multi-GB) upload; never taken together with the service mutex
-	chaindp_index_t *idx = nullptr;
-	uint64_t gen = 0;                   // generation of the image idx was made from
+	std::shared_ptr<DevIndex> idx;      // the copy of the NEWEST image a context of this GPU has seen
+	uint64_t gen = 0;                   // generation of the image idx was made from (only ever grows)
 	int64_t batches = 0, anchors = 0;   // work done on this GPU (under Service::mu)
 };
 
@@ -200,18 +210,22 @@ void service_loop(int device)
 		}
 		// this GPU's copy of the index image: made by whichever of its contexts gets here first, outside the service mutex
 		// (producers and the receiver keep going during the multi-GB upload)
-		chaindp_index_t *dev_index = nullptr;
+		// The batch holds a reference until it is done (index_ref is dropped at the end of this iteration): the other context of the
+		// GPU may replace the shared copy meanwhile.  A context that still holds an OLDER image than the shared copy (it took its
+		// packets just before the new image was sealed) makes a copy of its own for this one batch and leaves the shared one alone.
+		std::shared_ptr<DevIndex> index_ref;
 		if (image) {
+			auto upload = [&]() {
+				chaindp_index_t *ix = chaindp_index_create(device, image->blob(0).data(), image->blob(0).size(), image->blob(1).data(), image->blob(1).size(),
+				                                          image->blob(2).data(), image->blob(2).size(), image->blob(3).data(), image->blob(3).size());
+				if (!ix) { fprintf(stderr, "[chaindp-fpga] %s\n", chaindp_last_error(nullptr)); fail_hard("cannot load the index image onto the device"); }
+				return std::make_shared<DevIndex>(ix);
+			};
 			std::lock_guard<std::mutex> gl(share.mu);
-			if (!share.idx || share.gen != image_gen) {
-				if (share.idx) chaindp_index_destroy(share.idx);
-				share.idx = chaindp_index_create(device, image->blob(0).data(), image->blob(0).size(), image->blob(1).data(), image->blob(1).size(),
-				                                 image->blob(2).data(), image->blob(2).size(), image->blob(3).data(), image->blob(3).size());
-				if (!share.idx) { fprintf(stderr, "[chaindp-fpga] %s\n", chaindp_last_error(nullptr)); fail_hard("cannot load the index image onto the device"); }
-				share.gen = image_gen;
-			}
-			dev_index = share.idx;
+			if (!share.idx || image_gen > share.gen) { share.idx = upload(); share.gen = image_gen; }
+			index_ref = share.gen == image_gen ? share.idx : upload();
 		}
+		chaindp_index_t *const dev_index = index_ref ? index_ref->idx : nullptr;
 		const bool have_index = dev_index != nullptr;
 		// ---- parse (map.c:484-568 walks the packet the same way; fpga_writebuf_submit has checked that the headers fit)
 		for (size_t k = 0; k < pk.size(); ++k) {
@@ -321,7 +335,7 @@ void service_loop(int device)
 			}
 		};
 
-		const bool trace = getenv("CHAINDP_SHIM_TRACE") != nullptr;
+		static const bool trace = getenv("CHAINDP_SHIM_TRACE") != nullptr;       // (read once: getenv is not safe against a concurrent setenv)
 		auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 		while (!work.empty()) {
 			const Sub sb = work.front();
@@ -512,7 +526,7 @@ extern "C" void fpga_finalize(void)
 	{
 		std::lock_guard<std::mutex> lk(g.mu);
 		g.submit_q.clear(); g.result_q.clear(); g.inflight_bytes = 0;
-		for (auto &sh : g.gpus) if (sh->idx) { chaindp_index_destroy(sh->idx); sh->idx = nullptr; }
+		for (auto &sh : g.gpus) sh->idx.reset();         // (the workers are joined: no batch holds a reference any more)
 		g.up = false;
 	}
 	g.pool.destroy();
