@@ -6,12 +6,14 @@ on N MI355X, one process per GPU.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[3], "ava-ont self-overlap, 100k synthetic 10 kb reads, read-sharded
-across 8 GPUs"): every rank holds the same-size shard of that job, 12,500 reads (~6.1k anchors per
-read), generated on the host with the rank's read indices and the job's seed, uploaded to HBM
-BEFORE the clock starts.  A step = one pass of the whole device half over the resident shard:
-prepass (unit split, avg_qspan sums) + chain DP (f/p/v) + compaction into new_seed[], all HIP
-kernels, results left in HBM.  Reads are independent, so there is no collective on the data path
-(weak scaling); torch.distributed (RCCL) only provides the barrier and the max-over-ranks time.
+across 8 GPUs"): ONE fixed job of 100,000 reads (~6.1k anchors per read, 0.61 G anchors, 9.8 GB of
+anchors), cut over the N ranks by cumulative anchor count (--scaling strong, the default: at N=1 the
+whole job sits on one GPU, at N=8 each rank holds ~12,500 reads).  --scaling weak gives every rank
+its own 12,500 reads instead (per-GPU work fixed).  A rank generates its shard on the host with the
+job's seed and uploads it to HBM BEFORE the clock starts.  A step = one pass of the whole device half
+over the resident shard: prepass (unit split, avg_qspan sums) + chain DP (f/p/v) + compaction into
+new_seed[], all HIP kernels, results left in HBM.  Reads are independent, so there is no collective
+on the data path; torch.distributed (RCCL) only provides the barrier and the max-over-ranks time.
 
 One JSON line on rank 0: metric/value/unit as BASELINE.json names them, plus
   roofline     -- the chain-DP kernel against the HBM roofline: 24 algorithmic bytes per anchor
@@ -32,7 +34,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-READS_PER_GPU = 12_500          # 100k reads / 8 GPUs (configs[3])
+READS_PER_GPU = 12_500          # 100k reads / 8 GPUs (configs[3]): the weak-scaling shard, and the sub-batch of the side measurements
+JOB_READS = {"ava-ont": 100_000, "map-ont": 9_400, "skew": 24_000, "dense": 12_500}   # the fixed job of --scaling strong, by preset
 SEED = 20261004
 ALGO_BYTES_PER_ANCHOR = 24
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
@@ -43,7 +46,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads-per-gpu", type=int, default=READS_PER_GPU)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong: one fixed job (--job-reads) cut over the ranks by anchor count; weak: --reads-per-gpu reads on every rank")
+    ap.add_argument("--job-reads", type=int, default=0, help="reads of the fixed job (strong scaling); default by preset: 100000 for ava-ont (BASELINE configs[3])")
+    ap.add_argument("--reads-per-gpu", type=int, default=READS_PER_GPU, help="reads per rank (weak scaling)")
     ap.add_argument("--preset", default="ava-ont", help="generator + DP preset (ava-ont, map-ont, skew, dense)")
     ap.add_argument("--ring", type=int, default=0, help="LDS ring capacity override (128/256/512)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
@@ -82,12 +88,16 @@ def main():
     par = params.preset(dp_preset)
 
     # ---- this rank's shard of the job, generated on the host, then made resident in HBM
-    n_reads = args.reads_per_gpu
+    strong = args.scaling == "strong"
+    job_reads = (args.job_reads or JOB_READS.get(gen_preset, 100_000)) if strong else args.reads_per_gpu * world
     t_gen = time.time()
-    off, anchors = shard.generate_shard(gen_preset, rank, world, n_reads, SEED, threads=args.host_threads)
+    if strong:
+        off, anchors, _first = shard.generate_job_shard(gen_preset, rank, world, job_reads, SEED, threads=args.host_threads)
+    else:
+        off, anchors = shard.generate_shard(gen_preset, rank, world, args.reads_per_gpu, SEED, threads=args.host_threads)
     t_gen = time.time() - t_gen
     total = int(off[-1])
-    n_reads = len(off) - 1                                   # (the skewed job is dealt by anchor count: read counts differ per rank)
+    n_reads = len(off) - 1                                   # (a job dealt by anchor count: read counts differ per rank)
     dev = chaindp.Device(dev_index, max_anchors=total + 1, max_reads=n_reads + 1, ring=args.ring or None)
     t_up = time.time()
     dev.upload(off, anchors)
@@ -122,11 +132,16 @@ def main():
         dist.barrier()
 
     extras = {}
-    if rank == 0 and world == 1 and not args.no_extras:      # side measurements only in the single-GPU run
-        extras = measure_extras(torch, chaindp, dev, par, off, anchors, total)
-        if gen_preset == "ava-ont" and n_reads == READS_PER_GPU:
+    if rank == 0 and world == 1 and not args.no_extras:      # side measurements only in the single-GPU run, on one GPU's share of the job
+        ns = min(n_reads, READS_PER_GPU)
+        sub_off = np.ascontiguousarray(off[:ns + 1])
+        sub_a = anchors[:int(sub_off[-1])]
+        extras = measure_extras(torch, chaindp, dev, par, sub_off, sub_a, int(sub_off[-1]))
+        extras["side_measurements_on"] = f"the first {ns} reads of the job ({int(sub_off[-1])} anchors): one GPU's share at N=8"
+        if gen_preset == "ava-ont" and strong and job_reads == JOB_READS["ava-ont"]:
             extras["other_configs"] = other_configs(chaindp, params, shard, dev_index, args)
             extras["map_batch"] = measure_map_batch(chaindp, params, dev_index)
+            extras["packet_abi"] = measure_packet_abi(par, sub_off, sub_a)
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -144,15 +159,18 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
             "config": {
-                "workload": f"{gen_preset} synthetic anchors, {n_reads} reads x 10 kb per GPU "
-                            f"(shard of BASELINE configs[3]: 100k reads over 8 GPUs), DP preset {dp_preset}",
-                "reads_per_gpu": n_reads, "anchors_per_gpu": total, "anchors_total": total_all,
-                "units_per_gpu": stats["units"], "singletons_per_gpu": stats["singletons"],
+                "workload": (f"{gen_preset} synthetic anchors, ONE job of {job_reads} reads x 10 kb"
+                             + (" (BASELINE configs[3])" if gen_preset == "ava-ont" and job_reads == 100_000 else "")
+                             + f" cut over {world} GPU(s) by anchor count, DP preset {dp_preset}") if strong else
+                            (f"{gen_preset} synthetic anchors, {n_reads} reads x 10 kb per GPU "
+                             f"(weak scaling: every rank its own shard; at 8 GPUs the 100k reads of BASELINE configs[3]), DP preset {dp_preset}"),
+                "job_reads": job_reads, "reads_on_rank0": n_reads, "anchors_on_rank0": total, "anchors_total": total_all,
+                "units_on_rank0": stats["units"], "singletons_on_rank0": stats["singletons"],
                 "seed": SEED, "parallelism": f"reads sharded over {world} GPU(s), no collective",
                 "step": "prepass + chain DP + compaction (new_seed[]), inputs and outputs resident in HBM",
             },
@@ -162,8 +180,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(total),
                 "algorithmic_bytes_per_anchor": ALGO_BYTES_PER_ANCHOR, "anchors_per_launch": total,
                 "avg_launch_ms": dp_ms,
-                # what actually bounds the kernel: instruction issue
-                "issue": measured_issue(total, dp_ms),
+                # "bound" names the roofline the contract asks for (HBM); what actually limits the kernel is
+                # instruction issue, reported beside it
+                "limited_by": "VALU instruction issue (see issue)", "issue": measured_issue(total, dp_ms),
             },
             "kernel_ms": {"prepass": pre_ms, "chain_dp": dp_ms, "compact": cmp_ms},
             "host": {"generate_s": t_gen, "upload_s": t_up, "upload_GBps": total * 16 / t_up / 1e9 if t_up > 0 else None},
@@ -171,6 +190,12 @@ def main():
         out.update(extras)
         if "pair_evals_per_anchor" in extras:
             out["pair_evals_per_s"] = value * extras["pair_evals_per_anchor"]
+        st_pmc = stored_pmc_any()
+        if out["roofline"]["traffic"] is None and st_pmc is not None:
+            # the stored counters belong to another build of the kernels or another batch: say so instead of a silent null
+            out["roofline"]["traffic_stale"] = True
+            out["roofline"]["traffic_last_measured"] = {k: st_pmc.get(k) for k in ("hbm_bytes_per_launch", "anchors_per_launch", "kernel_source_sha16")}
+            out["roofline"]["kernel_source_sha16_now"] = kernel_source_sha16()
         if "device_copy_GBps" in extras:
             out["roofline"]["frac_of_measured_copy_bw"] = achieved / extras["device_copy_GBps"]
         if world == 1 and not args.no_cpu_baseline:
@@ -178,7 +203,8 @@ def main():
             # no published number exists for this metric, so vs_baseline stays null; the measured
             # ratios to the host's own CPU rate are reported under their own names
             cb = out["cpu_baseline"]
-            out["vs_cpu_all_cores"] = value / cb["best_value"] if cb["best_value"] > 0 else None
+            out["vs_cpu_best"] = value / cb["best_value"] if cb["best_value"] > 0 else None          # against the best thread count's rate
+            out["vs_cpu_all_cores"] = value / cb["value"] if cb["value"] > 0 else None             # against the all-logical-CPUs leg
             out["vs_cpu_single_core"] = value / cb["single_core_value"] if cb["single_core_value"] > 0 else None
         print(json.dumps(out), flush=True)
 
@@ -187,13 +213,37 @@ def main():
         dist.destroy_process_group()
 
 
+def cpu_reference_bounded(par, off, a, threads, budget_s=2.5):
+    """The reference's mm_chain_dp_fpga (oracle/_ref; the oracle's port where that build is absent) on `threads` host threads over a
+    bounded sample of a batch: a short probe sizes the sample to about budget_s seconds of wall time.  A reported baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    use_ref = ol.have_ref()
+    n_all = len(off) - 1
+    tot = int(off[-1])
+    n1 = int(np.searchsorted(off, max(tot // 64, 1), side="left"))
+    n1 = max(min(threads, n_all), min(n1, n_all))
+    so = np.ascontiguousarray(off[:n1 + 1])
+    th = max(1, min(threads, n1))
+    sec, _ = ol.time_top(par, so, a, threads=th, use_ref=use_ref)
+    rate = int(so[-1]) / max(sec, 1e-9)
+    n2 = int(np.searchsorted(off, min(tot, max(int(rate * budget_s), 1)), side="left"))
+    n2 = max(n1, min(n2, n_all))
+    so = np.ascontiguousarray(off[:n2 + 1])
+    th = max(1, min(threads, n2))
+    sec, _ = ol.time_top(par, so, a, threads=th, use_ref=use_ref)
+    return {"anchors_per_s": int(so[-1]) / max(sec, 1e-9), "threads": th, "kind": "reference" if use_ref else "port",
+            "sample": f"first {n2} reads ({int(so[-1])} anchors), one pass, per-read mm_chain_dp_fpga call", "seconds": sec}
+
+
 def other_configs(chaindp, params, shard, dev_index, args):
     """The other single-GPU shapes BASELINE.json names, same step (prepass + chain DP + compaction, resident), a few steps each:
-    configs[2] (map-ont vs a human-size reference, ~50 M anchors), configs[4] (skewed 1e2..1e5 anchors per read) and the WHOLE job
-    of configs[3] (100,000 reads, ~0.6 G anchors, ~10 GB of anchors) on one GPU.  Reported beside the headline, never as `value`."""
+    configs[2] (map-ont vs a human-size reference, ~50 M anchors), configs[4] (skewed 1e2..1e5 anchors per read), one GPU's share
+    (12,500 reads) of the configs[3] job -- round 1 and 2's headline workload --, and dense repeats.  Each with the reference's CPU
+    rate on the same batch beside it (bounded sample, --cpu-threads threads).  Reported beside the headline, never as `value`."""
     out = {}
     for name, gen, preset, reads in (("map_ont_50M", "map-ont", "map-ont", 9_400), ("skew_1e2_1e5", "skew", "ava-ont", 3_000),
-                                     ("full_100k_reads_1gpu", "ava-ont", "ava-ont", 100_000),
+                                     ("shard_12500_reads_1gpu", "ava-ont", "ava-ont", READS_PER_GPU),
                                      # dense repeats (scans of hundreds to tens of thousands of predecessors): a batch that is all
                                      # tail -- 200 units of 15-38 k anchors -- and ten times that
                                      ("dense_200_units", "dense", "ava-ont", 100), ("dense_2000_units", "dense", "ava-ont", 1_000)):
@@ -228,6 +278,12 @@ def other_configs(chaindp, params, shard, dev_index, args):
                     d.sync()
                     out[name]["ms_per_step_one_wave_per_unit"] = (time.perf_counter() - t0) / 2 * 1e3
                     out[name]["speedup_from_dense_kernel"] = out[name]["ms_per_step_one_wave_per_unit"] / out[name]["ms_per_step"]
+            if not args.no_cpu_baseline:
+                try:
+                    out[name]["cpu_reference"] = cpu_reference_bounded(par, off, a, args.cpu_threads)
+                    out[name]["vs_cpu_reference"] = out[name]["anchors_per_s"] / out[name]["cpu_reference"]["anchors_per_s"]
+                except Exception as e:  # noqa: BLE001
+                    out[name]["cpu_reference"] = {"error": repr(e)}
             del off, a
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": repr(e)}
@@ -292,6 +348,101 @@ def measure_map_batch(chaindp, params, dev_index, target_anchors=24_000_000):
                 "includes": "H2D of minimizers (pageable), collect_seed_hits + sort, prepass + chain DP + compaction, backtrack, mm_gen_regs, D2H of hits"}
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}
+
+
+def _replay_file(path, packets, blobs, flag, mid_occ, par):
+    import struct
+    with open(path, "wb") as fh:
+        fh.write(b"SHIMRPL1" + struct.pack("<6i", int(flag), int(mid_occ), par.bw, par.max_skip, par.min_sc, len(packets)))
+        for blob in blobs:
+            blob = np.ascontiguousarray(blob, np.uint8)
+            fh.write(struct.pack("<q", blob.size))
+            fh.write(blob.tobytes())
+        for pk in packets:
+            fh.write(struct.pack("<I", len(pk)))
+            fh.write(pk)
+
+
+def _run_replay(path, producers, reps, rounds, anchors_per_rep):
+    import subprocess
+    exe = os.path.join(ROOT, "minimap2_chaindp_amd", "csrc", "shim_replay")
+    r = subprocess.run([exe, path, str(producers), str(reps), str(rounds)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    if r.returncode != 0:
+        return {"error": f"shim_replay exited with {r.returncode}: {r.stderr[-300:]}"}
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    rounds_ = [ln for ln in lines if "round" in ln]
+    shim = next((ln["shim"] for ln in lines if "shim" in ln), None)
+    steady = rounds_[1:] or rounds_                                # the first round pays the first-use allocations (pinned pool, scratch)
+    best = min(steady, key=lambda d: d["seconds"])
+    secs = sorted(d["seconds"] for d in steady)
+    med = secs[len(secs) // 2]
+    return {"anchors_per_s": anchors_per_rep * reps / med, "best_round_anchors_per_s": anchors_per_rep * reps / best["seconds"],
+            "records_out_per_s": best["records_out"] / best["seconds"], "elements_in_per_s": best["elements_in"] / best["seconds"],
+            "anchors_per_round": anchors_per_rep * reps, "packets_per_round": best["packets"], "reads_per_packet": 8, "producers": producers,
+            "rounds": [round(d["seconds"], 5) for d in rounds_], "PCIe_GBps_in": best["bytes_in"] / best["seconds"] / 1e9,
+            "PCIe_GBps_out": best["records_out"] * 24 / best["seconds"] / 1e9, "err_reads": best["err_reads_so_far"],
+            "device_batches": shim["device_batches"] if shim else None, "per_gpu": shim["gpus"] if shim else None}
+
+
+def measure_packet_abi(par, off, anchors, target_anchors=20_000_000, producers=8):
+    """The product's real boundary: the reference's driver ABI (fpga.h:37-62).  A C host (tools/shim_replay.c, built by the csrc
+    Makefile) plays the reference's threads -- `producers` producer threads that get a driver buffer, memcpy a packet of 8 reads
+    into it and submit it (map.c:423-444), one receiver that walks and releases every result packet (fpga_chaindp.c:228-266) --
+    against libchaindp_hip.so in a process of its own.  Two packet kinds: anchor packets (type 0x41; the first reads of the bench
+    job, >= 20 M anchors per pass) and the reference's own minimizer packets (type 3) with the index image streamed through
+    fpga_load_index first (the reference's dump of an all-vs-all run when it is on the box, else the committed synthetic-repeat
+    fixture).  PCIe-inclusive steady-state rates (median round after the first); never `value`."""
+    import tempfile
+    from minimap2_chaindp_amd import fpga
+    out = {}
+    exe = os.path.join(ROOT, "minimap2_chaindp_amd", "csrc", "shim_replay")
+    if not os.path.exists(exe):
+        return {"error": "minimap2_chaindp_amd/csrc/shim_replay is not built (make -C minimap2_chaindp_amd/csrc)"}
+    tmpdir = tempfile.mkdtemp(prefix="chaindp_replay_")
+    try:
+        # ---- anchor packets
+        try:
+            n = int(np.searchsorted(off, target_anchors, side="left"))
+            n = max(8, min(n, len(off) - 1))
+            packets = [fpga.build_task_packet([(r, anchors[int(off[r]):int(off[r + 1])]) for r in range(k, min(k + 8, n))],
+                                              par.max_dist_x, par.max_dist_y) for k in range(0, n, 8)]
+            path = os.path.join(tmpdir, "anchors.rpl")
+            _replay_file(path, packets, [np.zeros(0, np.uint8)] * 4, 0, 0, par)
+            del packets
+            out["anchor_packets"] = _run_replay(path, producers, 6, 4, int(off[n]))
+            out["anchor_packets"]["bytes_in_per_anchor"], out["anchor_packets"]["input"] = 16, f"first {n} reads of the bench job"
+            os.unlink(path)
+        except Exception as e:  # noqa: BLE001
+            out["anchor_packets"] = {"error": repr(e)}
+        # ---- the reference's minimizer packets (type 3)
+        try:
+            big = os.path.join(ROOT, "tests", "golden", "_big", "big_avaont.npz")
+            src = big if os.path.exists(big) else os.path.join(ROOT, "tests", "golden", "seeds", "syn_repeats_avaont.npz")
+            g = np.load(src, allow_pickle=False)
+            pv = [int(x) for x in g["params"]]
+            from minimap2_chaindp_amd import params as P
+            mpar = P.ChainParams(max_dist_x=pv[0], max_dist_y=pv[1], bw=pv[2], max_skip=pv[3], min_sc=pv[4], is_cdna=pv[5], n_segs=1)
+            nr = len(g["bid"])
+            reads = [(r, g["mini"][g["mini_off"][r]:g["mini_off"][r + 1]], int(g["bid"][r]), int(g["qlen"][r])) for r in range(nr)]
+            packets = [fpga.build_task_packet(reads[k:k + 8], mpar.max_dist_x, mpar.max_dist_y, pkt_type=fpga.PKT_MINIMIZERS) for k in range(0, nr, 8)]
+            tot_a = int(g["a_off"][-1]) if "a_off" in g.files else len(g["anchors"])
+            reps = max(1, int(round(target_anchors / max(tot_a, 1))))
+            path = os.path.join(tmpdir, "minimizers.rpl")
+            _replay_file(path, packets, [g["img_B"], g["img_H"], g["img_V"], g["img_P"]], g["flag"], g["mid_occ"], mpar)
+            out["minimizer_packets"] = _run_replay(path, producers, reps, 4, tot_a)
+            out["minimizer_packets"]["minimizers_per_s"] = out["minimizer_packets"].get("elements_in_per_s")
+            out["minimizer_packets"]["input"] = f"{os.path.relpath(src, ROOT)} ({nr} reads, {int(g['mini_off'][-1])} minimizers -> {tot_a} anchors) x {reps} per round"
+            os.unlink(path)
+        except Exception as e:  # noqa: BLE001
+            out["minimizer_packets"] = {"error": repr(e)}
+    finally:
+        try:
+            os.rmdir(tmpdir)
+        except OSError:
+            pass
+    out["includes"] = ("producer memcpy into driver buffers, packet parsing, H2D by a gather kernel over the pinned packets, (seed collection,) prepass + "
+                       "chain DP + compaction, result packets assembled in pinned memory by a scatter kernel, receiver walk and release")
+    return out
 
 
 def measure_extras(torch, chaindp, dev, par, off, anchors, total):
@@ -426,6 +577,13 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+def stored_pmc_any():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def stored_pmc(anchors_per_launch):
     """PMC figures of the DP kernel from tools/profile.sh on this same workload (profiles/latest_traffic.json).  PMC collection
     cannot run inside the timed process, so they are quoted only if they were measured on THIS build of the kernels (hash of
@@ -445,8 +603,25 @@ def measured_traffic(anchors_per_launch):
     return t["hbm_bytes_per_launch"] if t else None
 
 
-# instruction-issue ceilings of the chip, measured by tools/issue_calib.hip (profiles/r02_issue_calib_*.json), G wave-instructions/s
-VALU_FULL_RATE, VALU_HALF_RATE, SALU_RATE = 962.0, 590.0, 574.0
+def issue_ceilings():
+    """Instruction-issue ceilings of the chip in G wave-instructions/s, from the calibration runs of tools/issue_calib.hip that are
+    committed under profiles/ (8 waves per SIMD, every CU busy): plain two-source VALU (v_add_u32), the slow VALU class (v_min3_i32:
+    three sources; SGPR operands, DPP and compares issue alike) and SALU (s_add_u32); mean over the runs."""
+    import glob
+    acc = {"v_add_u32": [], "v_min3_i32": [], "s_add_u32": []}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_issue_calib_*.json")))
+    for f in files:
+        try:
+            for r in json.load(open(f))["results"]:
+                if r.get("waves_per_simd") == 8 and r.get("kind") in acc:
+                    acc[r["kind"]].append(r["salu_Ginst_s"] if r["kind"].startswith("s_") else r["valu_Ginst_s"])
+        except Exception:  # noqa: BLE001
+            pass
+    if not all(acc.values()):
+        return None
+    m = {k: sum(v) / len(v) for k, v in acc.items()}
+    return {"valu_full": m["v_add_u32"], "valu_half": m["v_min3_i32"], "salu": m["s_add_u32"], "files": [os.path.relpath(f, ROOT) for f in files]}
+
 
 
 def measured_issue(anchors_per_launch, dp_ms):
@@ -455,15 +630,16 @@ def measured_issue(anchors_per_launch, dp_ms):
     three sources, DPP and compares run at half of it, so the VALU ceiling lies between the two figures; the scalar unit is
     shared by a CU's four SIMDs."""
     t = stored_pmc(anchors_per_launch)
-    if not t or dp_ms <= 0 or not t.get("valu_insts_per_launch"):
+    ceil = issue_ceilings()
+    if not t or not ceil or dp_ms <= 0 or not t.get("valu_insts_per_launch"):
         return None
     sec = dp_ms * 1e-3
     out = {"valu": {"insts_per_anchor": t["valu_insts_per_launch"] / anchors_per_launch, "achieved": t["valu_insts_per_launch"] / sec / 1e9,
-                    "ceiling_all_full_rate": VALU_FULL_RATE, "ceiling_all_half_rate": VALU_HALF_RATE},
-           "unit": "G wave-instructions/s", "ceilings_from": "tools/issue_calib.hip on MI355X (profiles/r02_issue_calib_*.json)"}
+                    "ceiling_all_full_rate": ceil["valu_full"], "ceiling_all_half_rate": ceil["valu_half"]},
+           "unit": "G wave-instructions/s", "ceilings_from": "tools/issue_calib.hip on MI355X: " + ", ".join(ceil["files"])}
     if t.get("salu_insts_per_launch"):
         out["salu"] = {"insts_per_anchor": t["salu_insts_per_launch"] / anchors_per_launch, "achieved": t["salu_insts_per_launch"] / sec / 1e9,
-                       "ceiling": SALU_RATE, "frac": t["salu_insts_per_launch"] / sec / 1e9 / SALU_RATE}
+                       "ceiling": ceil["salu"], "frac": t["salu_insts_per_launch"] / sec / 1e9 / ceil["salu"]}
     return out
 
 

@@ -102,6 +102,10 @@ void  fpga_load_index(void *addr, int size, int type);
  * merged into one device batch at most, and the in-flight byte budget after which
  * fpga_get_writebuf_thread answers NULL ("busy, retry": map.c:439-441). */
 void chaindp_fpga_configure(int n_gpus, int max_packets_per_batch, unsigned long max_inflight_bytes);
+/* Service groups, before fpga_init: by default one per GPU in use.  n_groups > GPUs puts group k on GPU k mod GPUs, each group with
+ * service contexts, index copy and counters of its own: the node-level dispatch (a packet stream shared by several groups) can be
+ * exercised on a box with one GPU.  0 = default. */
+void chaindp_fpga_configure_groups(int n_groups);
 /* Capacity of one device batch (per service context; defaults 32 Mi anchors, 512 Ki reads), before fpga_init.  A read
  * with more anchors than that -- or, for minimizer packets, more seeds -- is answered with err_flag = 1 (map.c:933-944); a
  * batch whose seeds do not fit is split and retried. */
@@ -109,7 +113,8 @@ void chaindp_fpga_configure_capacity(int64_t max_anchors_per_batch, int64_t max_
 /* Counters since fpga_init: st[0] packets, st[1] reads, st[2] anchors, st[3] device batches,
  * st[4] reads answered err_flag=1. */
 void chaindp_fpga_stats(int64_t st[5]);
-/* Per GPU: st[0] device batches, st[1] anchors it has chained.  Returns the number of GPUs in use, -1 on a bad index.
+/* Per GPU (per service group, see above): st[0] device batches, st[1] anchors it has chained.  Returns the number of GPUs (groups)
+ * in use, -1 on a bad index.
  * Service threads take packets when they are free, so the node's GPUs split the stream by the work they get done. */
 int chaindp_fpga_stats_gpu(int gpu, int64_t st[2]);
 

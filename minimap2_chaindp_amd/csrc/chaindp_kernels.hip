@@ -605,7 +605,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 		const int n_segs = n_segs_pr ? n_segs_pr[u.read] : par.n_segs;
 		c.base = u.start; c.read = u.read; c.deep_n = 0;
 		c.rel0 = (int)(u.start - rs);
-		c.avgd = (double)((float)(uint64_t)(sq & ~(SUMQ_SEG_FLAG | SUMQ_LUT16_FLAG)) / (float)(int64_t)(re - rs));   // chain.c:241: f32 divide of converted u64 and i64
+		c.avgd = (double)((float)(uint64_t)(sq & ~SUMQ_FLAGS) / (float)(int64_t)(re - rs));   // chain.c:241: f32 divide of converted u64 and i64
 		c.seg_rule = n_segs > 1 && !par.is_cdna;                   // chain.c:261
 		const bool general = par.is_cdna || n_segs > 1 || (sq & SUMQ_SEG_FLAG) || lut == nullptr || !x32_ok
 		                     || par.max_dist_x < 1 || par.max_dist_y < 0;

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_rea
 			const int64_t rs = off[r], re = off[r + 1];
 			span = span_of_hi((uint32_t)(an.y >> 32));
 			if (seg_of_hi((uint32_t)(an.y >> 32)) != 0) atomicOr(&sumq[r], SUMQ_SEG_FLAG);   // rare: multi-segment reads only
+			if (span == 0) atomicOr(&sumq[r], SUMQ_SPAN0_FLAG);                                // (never, in minimap2's own anchors: q_span is the k-mer span)
 			start = g == rs || an.x - xprev > maxx;
 			const bool next_starts = g + 1 >= re || xnext - an.x > maxx;
 			single = start && next_starts;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void k_build_lut(Params par, int64_t n_reads, 
 	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
 		const int64_t n = off[r + 1] - off[r];
 		if (n <= 0) continue;
-		const float avg = (float)(uint64_t)(sumq[r] & ~(SUMQ_SEG_FLAG | SUMQ_LUT16_FLAG)) / (float)n;   // chain.c:241
+		const float avg = (float)(uint64_t)(sumq[r] & ~SUMQ_FLAGS) / (float)n;   // chain.c:241
 		const double avgd = (double)avg;
 		for (int dd = threadIdx.x; dd <= par.bw; dd += blockDim.x) {
 			const int lg = dd ? 31 - __builtin_clz((unsigned)dd) : 0;

@@ -11,18 +11,27 @@
 // instructions; the scalar unit only combines 64-bit lane masks (both halves at once) and branches.
 //
 // What it computes is exactly run_unit_fast of chaindp_kernels.hip (reference chain.c:246-284 for reads with one
-// segment, not cDNA, bw <= 511), with the same four derivations on 32-lane chunks.  Units it
+// segment, not cDNA, bw <= 511, every q_span > 0), with the same four derivations on 32-lane chunks.  Units it
 // does not take -- general-variant reads, and any unit whose scan needs a predecessor older than its LDS ring (64
 // anchors) -- are appended to a leftover list and run by k_chain_units afterwards, from scratch.
 //
+// Round 3: a half's anchors enter and leave in tiles of 64, and the per-tile service (next tile in, finished tile's f/p/v out,
+// unit switch) is done by ALL 64 lanes of the wave for one half at a time -- it was 32 anchors by the half's own 32 lanes with the
+// other half idle, a third of every wave's time and 30 % of its vector instructions.  Scores are kept minus one inside the kernel
+// (the PF ring holds f - 1, the current anchor's floor is q_span - 1; chain.c:251,274 compare the same way when both sides are
+// shifted), so that a pass needs q_span - 1 only; reads with a zero q_span go to k_chain_units.
+//
 // LDS per wave (dynamic segment, starts at byte 0; h = half):
 //   XY  [128 slots][2 halves] 8 B   x.lo+1, qpos+1 of anchor (slot = i & 127), written a whole tile at a time
-//   PF  [ 64 slots][2 halves] 8 B   4*p (unit-relative, -4 = none), f of anchor (slot = i & 63)
-//   MK  [2 halves][65 + pad] 4 B    marks by distance: word d-1 holds the scan tag of the anchor d behind; word 64 = sink
+//   PF  [ 64 slots][2 halves] 8 B   4*p (unit-relative, -4 = none), f - 1 of anchor (slot = i & 63)
 //   V   [ 64 slots][2 halves] 4 B   v | "emitted at its own step" << 31
-//   CUR [2 halves][32] 16 B         the current tile's anchors as a pass wants them: x.lo, qpos, q_span - 1, q_span
+//   XQ  [2 halves][64] 8 B          the current tile's anchors as a pass wants them: x.lo, qpos
 //   LUT [2 halves][512] int8        the read's table of 1 - cost (reads whose costs do not fit a byte go to k_chain_units)
-//   ST  [2 halves] 64 B             the half's cold state (TwinCold)
+//   ST  [2 halves] 56 B             the half's cold state (TwinCold) and what a scan carries into its second chunk
+//   MK  [2 halves][65] 4 B          marks by distance: word d-1 holds the scan tag of the anchor d behind; word 64 = sink
+//   SP  [2 halves][64] 1 B          q_span - 1 of the current tile's anchors (entry n of XQ at byte a has its SP byte at a / 8 + const)
+// 6392 bytes.  LDS is handed out in pieces of 1280 bytes on this chip (tools/lds_occupancy_probe.hip measures how many workgroups
+// a CU holds; the occupancy API does not know): 6400 bytes are the most that leave 24 waves per CU, i.e. six per SIMD.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
@@ -36,30 +45,20 @@ namespace chaindp {
 
 #define TW_XY 0u
 #define TW_PF 2048u
-#define TW_MK 3072u
-#define TW_MK_HALF 272u
-#define TW_V 3616u
-#define TW_CUR 4128u
-#define TW_CUR_HALF 512u
-#define TW_LUT 5152u
+#define TW_V 3072u
+#define TW_XQ 3584u
+#define TW_XQ_HALF 512u
+#define TW_LUT 4608u
 #define TW_LUT_HALF 512u
-#define TW_ST 6176u
-#define TW_LDS_BYTES 6304u
-// ring addressing.  TW_EXP_DEINT: XY as [half][128] 8 B and PF as [half][64] 8 B (a half's 32 lanes read 256 contiguous bytes:
-// no bank conflict inside the lane group) instead of [slot][half]
-#ifdef TW_EXP_DEINT
-#define TW_SH 3
-#define TW_XYA(t) ((((t)) & 0x3f8u) | c_xyb)
-#define TW_PFA(t) ((((t)) & 0x1f8u) | c_pfb)
-#define TW_XYS(slot, hh) (((uint32_t)(slot) << 3) + TW_XY + 1024u * (uint32_t)(hh))
-#define TW_PFS(slot, hh) (((uint32_t)(slot) << 3) + TW_PF + 512u * (uint32_t)(hh))
-#else
-#define TW_SH 4
-#define TW_XYA(t) ((((t)) & 0x7f8u) + TW_XY)
-#define TW_PFA(t) ((((t)) & 0x3f8u) + TW_PF)
-#define TW_XYS(slot, hh) (((uint32_t)(slot) << 4 | (uint32_t)(hh) << 3) + TW_XY)
-#define TW_PFS(slot, hh) (((uint32_t)(slot) << 4 | (uint32_t)(hh) << 3) + TW_PF)
-#endif
+#define TW_ST 5632u
+#define TW_ST_HALF 56u
+#define TW_MK 5744u
+#define TW_MK_HALF 260u
+#define TW_SP 6264u
+#define TW_SP_HALF 64u
+#define TW_SP_OF_XQ (TW_SP - TW_XQ / 8u)  // SP address = (XQ address >> 3) + this
+#define TW_LDS_BYTES 6392u
+#define TW_TILE 64                      // anchors a half takes in / flushes at a time
 #define TW_RING 64                      // predecessors a scan can reach in this kernel (two chunks of 32)
 #define TW_QCH 8                        // units a half takes from the queue at a time
 
@@ -74,6 +73,7 @@ typedef uint32_t tw_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ tw_u32x2 tw_ld64(uint32_t a) { return *TW_LDS(const tw_u32x2, a); }
 __device__ __forceinline__ int tw_ld32(uint32_t a) { return *TW_LDS(const int, a); }
 __device__ __forceinline__ int tw_ld_i8(uint32_t a) { return (int)*TW_LDS(const signed char, a); }
+__device__ __forceinline__ int tw_ld_u8(uint32_t a) { return (int)*TW_LDS(const unsigned char, a); }
 __device__ __forceinline__ tw_u32x4 tw_ld128(uint32_t a) { return *TW_LDS(const tw_u32x4, a); }
 __device__ __forceinline__ void tw_st64(uint32_t a, uint32_t x, uint32_t y) { tw_u32x2 t; t.x = x; t.y = y; *TW_LDS(tw_u32x2, a) = t; }
 __device__ __forceinline__ void tw_st32(uint32_t a, int v) { *TW_LDS(int, a) = v; }
@@ -210,7 +210,7 @@ struct TwinArgs {
 
 // the state of a half that only the service path needs lives in LDS (TW_ST + 64 h), so that the pass loop carries
 // nothing but what a pass reads
-struct TwinCold {
+struct TwinCold {                     // 40 bytes at TW_ST + 56 h (8-byte aligned: read and written as 64-bit words)
 	int64_t next;                     // next unit of this half (grid-stride over pairs)
 	int64_t base;                     // global index of the unit's first anchor
 	uint64_t x_carry;                 // x of the previous tile's last anchor
@@ -221,13 +221,12 @@ struct TwinCold {
 struct TwinHot {
 	uint32_t S;                       // 16 * jtop + 8h, jtop = i - 1 - 32c: ring offset of lane 0's predecessor
 	uint32_t m4;                      // 4 * (i - 1) + mark base: mark distance base and the scan's tag
-	uint32_t pc, pend;                // CUR entry of the current anchor; end of the tile's entries
-	// constant while a half is in its first chunk:
-	int maxf;                         // running max of the scan (chain.c:274) carried into a second chunk
-	uint32_t kb4;                     // 128 * c
-	int maxj4, nskip;                 // 4 * max_j (-4: none); n_skip carried into the chunk
-	int slow;                         // second chunks the unit has needed so far
+	uint32_t pc, pend;                // XQ entry of the current anchor; end of the tile's entries
 };
+// What a scan carries into its second chunk (one scan in thirty) is not worth registers: it sits behind the half's cold state
+// (TW_ST + 56 h + 40): 4 * max_j (-4: none), the running max of the scan (chain.c:274) minus one, n_skip, and the second chunks
+// the unit has needed so far.
+#define TW_CARRY 40u
 
 // in-kernel stamps (where a wave's time goes): compiled in only with -DCHAINDP_TWIN_STAMPS, because even switched off they cost
 // registers the kernel does not have to spare (make -C csrc stamps; then run with CHAINDP_TWIN_STAMP=1)
@@ -255,23 +254,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 	const int lane = threadIdx.x;
 	const bool hi_half = lane >= 32;
 	const int h = lane >> 5, hl = lane & 31;
-	const uint64_t my_half = hi_half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
 
 	// ---- per-lane constants (vector registers on purpose, see TW_VREG)
-	uint32_t L16 = (uint32_t)hl << TW_SH;
+	uint32_t L16 = (uint32_t)hl << 4;
 	const uint32_t mkbase = TW_MK + TW_MK_HALF * (uint32_t)h;      // this half's mark words
-	const uint32_t curbase = TW_CUR + TW_CUR_HALF * (uint32_t)h;   // this half's CUR entries
+	const uint32_t curbase = TW_XQ + TW_XQ_HALF * (uint32_t)h;     // this half's XQ entries
 	uint32_t c_mkbase = mkbase;
 	uint32_t c_far = mkbase + 256u;                                // its sink word
 	uint32_t c_own = mkbase + ((uint32_t)hl << 2);                 // lane's own mark word in chunk 0
 	uint32_t c_lut = TW_LUT + TW_LUT_HALF * (uint32_t)h;
-#ifdef TW_EXP_DEINT
-	uint32_t c_8h = 0u;
-	uint32_t c_xyb = TW_XY + 1024u * (uint32_t)h, c_pfb = TW_PF + 512u * (uint32_t)h;
-	TW_VREG(c_xyb); TW_VREG(c_pfb);
-#else
 	uint32_t c_8h = (uint32_t)h << 3;
-#endif
 	uint32_t c_M = (uint32_t)g.par.max_dist_x;
 	uint32_t c_bw = (uint32_t)g.par.bw;
 	uint32_t c_cbw = c_M - 1u > c_bw ? c_M - 1u - c_bw : 0u;
@@ -301,128 +293,132 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 	                       ((uint64_t)(int64_t)g.par.max_dist_x + 1) * 129ull < (1ull << 31) && g.par.bw + 1 <= (int)TW_LUT_HALF && !g.force_left;
 
 	TwinHot u;
-	u.S = 0; u.m4 = 0; u.pc = curbase; u.pend = curbase; u.maxf = 0; u.kb4 = 0; u.maxj4 = -4; u.nskip = 0; u.slow = 0;
+	u.S = 0; u.m4 = 0; u.pc = curbase; u.pend = curbase;
 	uint64_t live_m = ~0ull;                                       // halves that still have (or may get) work
 	uint64_t contm = 0;                                            // halves that are in their second (= last) chunk
-	const uint32_t st_addr = TW_ST + 64u * (uint32_t)h;
+	const uint32_t st_addr = TW_ST + TW_ST_HALF * (uint32_t)h;
 #define TW_COLD (*TW_LDS(TwinCold, st_addr))
 	if (hl == 0) {
 		const uint32_t nx = TW_QCH * (2u * blockIdx.x + (uint32_t)h);                   // the half's first chunk of units: dealt statically
-		tw_st128(st_addr, nx, nx + TW_QCH, 0u, 0u);                                     // TwinCold: next (low word: next unit, high word: end of the chunk), base
-		tw_st128(st_addr + 16u, 0u, 0u, 0u, 0u);                                        // x_carry, rel0, room
-		tw_st64(st_addr + 32u, 0u, (uint32_t)-32);                                      // read, tile0
+		tw_st64(st_addr, nx, nx + TW_QCH); tw_st64(st_addr + 8u, 0u, 0u);               // TwinCold: next (low word: next unit, high word: end of the chunk), base
+		tw_st64(st_addr + 16u, 0u, 0u); tw_st64(st_addr + 24u, 0u, 0u);                 // x_carry, rel0, room
+		tw_st64(st_addr + 32u, 0u, (uint32_t)-TW_TILE);                                 // read, tile0
+		tw_st64(st_addr + TW_CARRY, 0xfffffffcu, 0u); tw_st64(st_addr + TW_CARRY + 8u, 0u, 0u);   // carry, second chunks so far
 	}
 	wave_mem_fence();
 
 	TW_STAMP(unsigned long long st_t0 = 0; unsigned int st_service = 0, st_n_service = 0, st_n_fast = 0, st_flush = 0, st_unit = 0, st_n_unit = 0, st_head = 0, st_take = 0, st_tail = 0;)   // (32-bit sums: a wave's ticks fit, and the build has no registers to spare)
-	ulonglong2 an_nx = make_ulonglong2(0, 0);                      // this lane's anchor of its half's NEXT tile, requested a tile ahead
+	uint64_t nx0_x = 0, nx0_y = 0, nx1_x = 0, nx1_y = 0;           // each half's NEXT tile, requested a tile ahead (one anchor per lane; zeros where the unit has none)
 
-	// One service round for the halves in `svc`, whose tile is exhausted (or which have no unit yet).  One half at a time, with
-	// only its 32 lanes active: everything that is per half (the cold state, the unit being picked, loop conditions) is then
-	// wave-uniform and lives in scalar registers, loads by scalar address go through the scalar cache, and the loops are scalar
-	// branches.  Order: the unit's NEXT tile (requested a tile ago) is taken first -- before the finished tile's f/p/v are stored,
-	// so that nothing waits for those stores --, then the finished tile is flushed; a half whose unit is over picks its next
-	// unit and loads that one's first tile (the one load whose latency is not hidden).  Once per 32 anchors and half.
+	// One service round for the halves in `svc`, whose tile is exhausted (or which have no unit yet).  One half at a time, by ALL 64
+	// lanes of the wave (a tile is 64 anchors, one per lane): everything that is per half (the cold state, the unit being picked,
+	// loop conditions) is wave-uniform and lives in scalar registers, loads by scalar address go through the scalar cache, and the
+	// loops are scalar branches; what goes back into the half's hot state is selected into its 32 lanes (TW_SEL by `hm`).  Order:
+	// the unit's NEXT tile (requested ahead) is taken first -- before the finished tile's f/p/v are stored, so that nothing waits
+	// for those stores --, then the finished tile is flushed; a half whose unit is over picks its next unit and loads that one's
+	// first tile.  Once per 64 anchors and half.
 	auto service = [&](uint64_t svc) {
 		wave_mem_fence();
-		bool lane_retired = false;
+		uint64_t retired = 0;
 		for (int hs = 0; hs < 2; ++hs) {
 			if (((svc >> (32 * hs)) & 1ull) == 0) continue;
-			if (h != hs) continue;
 			TW_STAMP_B(const unsigned long long th0 = g.stamp ? TW_NOW() : 0;)
-			const uint32_t sa = TW_ST + 64u * (uint32_t)hs;
-			const tw_u32x4 cw0 = tw_ld128(sa), cw1 = tw_ld128(sa + 16u);
-			const tw_u32x2 cw2 = tw_ld64(sa + 32u);
+			const uint64_t hm = hs ? 0xffffffff00000000ull : 0x00000000ffffffffull;   // the lanes that carry this half's hot state
+			const uint32_t sa = TW_ST + TW_ST_HALF * (uint32_t)hs;
+			const uint32_t curb = TW_XQ + TW_XQ_HALF * (uint32_t)hs, spb = TW_SP + TW_SP_HALF * (uint32_t)hs;   // (SP: a byte per anchor)
+			const uint32_t mkb = TW_MK + TW_MK_HALF * (uint32_t)hs, lutb = TW_LUT + TW_LUT_HALF * (uint32_t)hs;
+			const tw_u32x2 cw0 = tw_ld64(sa), cw1 = tw_ld64(sa + 8u), cw2 = tw_ld64(sa + 16u), cw3 = tw_ld64(sa + 24u), cw4 = tw_ld64(sa + 32u);
 			int64_t c_next = (int64_t)((uint64_t)TW_UNI(cw0.y) << 32 | TW_UNI(cw0.x));
-			int64_t c_base = (int64_t)((uint64_t)TW_UNI(cw0.w) << 32 | TW_UNI(cw0.z));
-			uint64_t c_xcarry = (uint64_t)TW_UNI(cw1.y) << 32 | TW_UNI(cw1.x);
-			int c_rel0 = (int)TW_UNI(cw1.z), c_room = (int)TW_UNI(cw1.w), c_read = (int)TW_UNI(cw2.x), c_tile0 = (int)TW_UNI(cw2.y);
-			const int cnt_prev = (int)TW_UNI((u.pend - curbase) >> 4);   // anchors of the tile that has just been scored
+			int64_t c_base = (int64_t)((uint64_t)TW_UNI(cw1.y) << 32 | TW_UNI(cw1.x));
+			uint64_t c_xcarry = (uint64_t)TW_UNI(cw2.y) << 32 | TW_UNI(cw2.x);
+			int c_rel0 = (int)TW_UNI(cw3.x), c_room = (int)TW_UNI(cw3.y), c_read = (int)TW_UNI(cw4.x), c_tile0 = (int)TW_UNI(cw4.y);
+			const int cnt_prev = (int)(((uint32_t)__builtin_amdgcn_readlane((int)u.pend, 32 * hs) - curb) >> 3);   // anchors of the tile that has just been scored
+			const int slow_h = (int)TW_UNI((uint32_t)tw_ld32(sa + TW_CARRY + 12u));
 			const int tile_prev = c_tile0, rel0_prev = c_rel0;
 			const int64_t base_prev = c_base;
 			bool live = true;
 
 			// takes a tile's anchors (one per lane, raw mm128_t) into the half's LDS: where the unit ends (first gap > max_dist_x,
-			// chain.c:252), XY ring (the anchors as predecessors), CUR (as the current anchor); requests the tile after it.
-			// Returns the anchors the tile holds (0: the unit ended exactly at its start).
-			auto take_tile = [&](ulonglong2 an) -> int {
-				const int i_lane = c_tile0 + hl;
+			// chain.c:252), XY ring (the anchors as predecessors), XQ / SP (as the current anchor).  Returns the anchors the tile holds
+			// (0: the unit ended exactly at its start).
+			auto take_tile = [&](const uint64_t an_x, const uint64_t an_y) -> int {
+				const int i_lane = c_tile0 + lane;
 				const bool have = i_lane < c_room;
 				uint64_t xp;
 				{
-					uint32_t lo = (uint32_t)wave_shift_up1((int)(uint32_t)an.x, 0), hi = (uint32_t)wave_shift_up1((int)(uint32_t)(an.x >> 32), 0);
-					if (hl == 0) { lo = (uint32_t)c_xcarry; hi = (uint32_t)(c_xcarry >> 32); }
+					uint32_t lo = (uint32_t)wave_shift_up1((int)(uint32_t)an_x, 0), hi = (uint32_t)wave_shift_up1((int)(uint32_t)(an_x >> 32), 0);
+					if (lane == 0) { lo = (uint32_t)c_xcarry; hi = (uint32_t)(c_xcarry >> 32); }
 					xp = (uint64_t)hi << 32 | lo;
 				}
-				const bool stop = !have || (i_lane > 0 && an.x - xp > maxx);
-				const uint64_t stop_m = __builtin_amdgcn_ballot_w64(stop);                      // (only this half's lanes are active)
-				const uint32_t stop_h = hs ? (uint32_t)(stop_m >> 32) : (uint32_t)stop_m;
-				const int cnt = stop_h ? __builtin_ctz(stop_h) : 32;
-				c_xcarry = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(an.x >> 32), 32 * hs + 31) << 32 |
-				           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)an.x, 32 * hs + 31);
-				u.pc = curbase; u.pend = curbase + ((uint32_t)cnt << 4);
+				const bool stop = !have || (i_lane > 0 && an_x - xp > maxx);
+				const uint64_t stop_m = __builtin_amdgcn_ballot_w64(stop);
+				const int cnt = stop_m ? __builtin_ctzll(stop_m) : TW_TILE;
+				c_xcarry = readlane_u64(an_x, 63);
+				u.pc = TW_SEL(hm, curb, u.pc); u.pend = TW_SEL(hm, curb + ((uint32_t)cnt << 3), u.pend);
 				if (cnt == 0) return 0;
 				wave_mem_fence();
-				if (hl < cnt) {
-					const int sp = span_of_hi((uint32_t)(an.y >> 32));
-					tw_st64(TW_XYS((uint32_t)i_lane & 127u, hs), (uint32_t)an.x + 1u, (uint32_t)an.y + 1u);
-					tw_st128(curbase + ((uint32_t)hl << 4), (uint32_t)an.x, (uint32_t)an.y, (uint32_t)(sp - 1), (uint32_t)sp);
+				if (lane < cnt) {
+					const int sp = span_of_hi((uint32_t)(an_y >> 32));
+					tw_st64((((uint32_t)i_lane & 127u) << 4 | (uint32_t)hs << 3) + TW_XY, (uint32_t)an_x + 1u, (uint32_t)an_y + 1u);
+					tw_st64(curb + ((uint32_t)lane << 3), (uint32_t)an_x, (uint32_t)an_y);
+					tw_st8(spb + (uint32_t)lane, sp - 1);
 				}
 				wave_mem_fence();
-				// the tile after this one: the load is issued now and read at the half's next service, 32 anchors of work later
-				an_nx = make_ulonglong2(0, 0);
-				if (cnt == 32 && i_lane + 32 < c_room) an_nx = g.a[c_base + i_lane + 32];
+				// the tile after this one: the load is issued now and read at the half's next service, 64 anchors of work later
+				uint64_t rx = 0, ry = 0;
+				if (cnt == TW_TILE && i_lane + TW_TILE < c_room) { const ulonglong2 t = g.a[c_base + i_lane + TW_TILE]; rx = t.x; ry = t.y; }
+				if (hs) { nx1_x = rx; nx1_y = ry; } else { nx0_x = rx; nx0_y = ry; }
 				return cnt;
 			};
 
 			// ---- the unit goes on?
-			bool goes_on = cnt_prev == 32 && c_tile0 + 32 < c_room;
-			if (goes_on && c_tile0 + 32 >= 64 && (int)TW_UNI(u.slow) * 8 > c_tile0 + 32) {
+			bool goes_on = cnt_prev == TW_TILE && c_tile0 + TW_TILE < c_room;
+			if (goes_on && slow_h * 8 > c_tile0 + TW_TILE) {
 				// a unit that keeps needing second chunks (more than one anchor in eight) is cheaper in k_chain_units: hand the rest
 				// of it -- that is, all of it, from scratch -- over
-				if (hl == 0) { Unit un; un.start = c_base; un.read = c_read; un.len = c_room; g.left[atomicAdd(g.left_cnt, 1u)] = un; }
+				if (lane == 0) { Unit un; un.start = c_base; un.read = c_read; un.len = c_room; g.left[atomicAdd(g.left_cnt, 1u)] = un; }
 				goes_on = false;
 			}
 			if (goes_on) {
-				c_tile0 += 32;
-				if (take_tile(an_nx) == 0) goes_on = false;                // it ended exactly on the boundary
+				c_tile0 += TW_TILE;
+				if (take_tile(hs ? nx1_x : nx0_x, hs ? nx1_y : nx0_y) == 0) goes_on = false;   // it ended exactly on the boundary
 			}
 			TW_STAMP_B(if (g.stamp) st_take += (unsigned int)(TW_NOW() - th0);)
 			// ---- flush the finished tile
 			TW_STAMP_A(const unsigned long long tf0 = g.stamp ? TW_NOW() : 0;)
 			if (cnt_prev > 0) {
-				const int i_lane = tile_prev + hl;                           // this lane's anchor of the finished tile
-				const bool have = hl < cnt_prev;
+				const int i_lane = tile_prev + lane;                         // this lane's anchor of the finished tile
+				const bool have = lane < cnt_prev;
 				const int64_t gi = base_prev + i_lane;
 				int fi = 0, p4 = -4;
 				if (have) {
-					const tw_u32x2 pf = tw_ld64(TW_PFS((uint32_t)i_lane & 63u, hs));
-					p4 = (int)pf.x; fi = (int)pf.y;
+					const tw_u32x2 pf = tw_ld64((((uint32_t)i_lane & 63u) << 4 | (uint32_t)hs << 3) + TW_PF);
+					p4 = (int)pf.x; fi = (int)pf.y + 1;                      // (the ring holds f - 1)
 				}
 				const int pi = p4 >> 2;                                      // unit-relative predecessor, -1 = none
 				int val = fi, ptr = have ? pi : -1;
 				const bool ext = ptr >= 0 && ptr < tile_prev;                // predecessor in an earlier tile: its v is final, in the V ring
 				int vext = 0;
 				if (ext) {
-					vext = tw_ld32((((uint32_t)ptr & 63u) << 3 | (uint32_t)h << 2) + TW_V);
+					vext = tw_ld32((((uint32_t)ptr & 63u) << 3 | (uint32_t)hs << 2) + TW_V);
 					val = max(val, vext & 0x7fffffff);
 					ptr = -1;
 				}
 				const bool ext_self = ext && vext < 0;                       // (bit 31 of a V entry: the anchor was emitted at its own step)
-				for (int r = 0; r < 5; ++r) {                                // v[i] = max(f[i], v[p[i]]) (chain.c:284) by pointer doubling over the tile
+				for (int r = 0; r < 6; ++r) {                                // v[i] = max(f[i], v[p[i]]) (chain.c:284) by pointer doubling over the tile
 					if (__builtin_amdgcn_ballot_w64(ptr >= tile_prev) == 0) break;
-					const int src = ((ptr >= tile_prev ? ptr - tile_prev : hl) + (hs << 5)) << 2;
+					const int src = (ptr >= tile_prev ? ptr - tile_prev : lane) << 2;
 					const int pv = __builtin_amdgcn_ds_bpermute(src, val);
 					const int pp = __builtin_amdgcn_ds_bpermute(src, ptr);
 					if (ptr >= tile_prev) { val = max(val, pv); ptr = pp; }
 				}
 				const bool self = val >= g.par.min_sc || pi >= 0;            // emitted at its own step (chain.c:304)
 				// is the predecessor emitted at its own step?  in-tile predecessors: ask their lane
-				const int srcp = ((pi >= tile_prev ? pi - tile_prev : hl) + (hs << 5)) << 2;
+				const int srcp = (pi >= tile_prev ? pi - tile_prev : lane) << 2;
 				const int pself_in = __builtin_amdgcn_ds_bpermute(srcp, self ? 1 : 0);
 				const bool pred_self = ext ? ext_self : pself_in != 0;
 				wave_mem_fence();
-				if (have) tw_st32((((uint32_t)i_lane & 63u) << 3 | (uint32_t)h << 2) + TW_V, val | (self ? INT_MIN : 0));
+				if (have) tw_st32((((uint32_t)i_lane & 63u) << 3 | (uint32_t)hs << 2) + TW_V, val | (self ? INT_MIN : 0));
 				wave_mem_fence();
 				// (first_child[] of the whole batch is NO_CHILD when this kernel starts -- one memset by the host -- so that no tile has
 				// to store it and wait for the store before its children's atomics)
@@ -447,52 +443,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 						// the chunk is used up: the next TW_QCH units nobody has taken (the list is longest first, so the two halves of a
 						// wave, and all waves, work on units of similar length at any time and run out of work together)
 						uint32_t q0 = 0;
-						if (hl == 0) q0 = atomicAdd(g.queue, (unsigned int)TW_QCH);
+						if (lane == 0) q0 = atomicAdd(g.queue, (unsigned int)TW_QCH);
 						nx = TW_UNI(q0); ne = nx + TW_QCH;
 					}
 					if ((int64_t)nx >= n_units) { c_next = (int64_t)((uint64_t)ne << 32 | nx); live = false; break; }
 					un = g.units[nx];
 					c_next = (int64_t)((uint64_t)ne << 32 | (nx + 1u));
 					const unsigned long long sq = g.sumq[un.read];
-					const bool general = !params_ok || (sq & (SUMQ_SEG_FLAG | SUMQ_LUT16_FLAG)) || g.par.n_segs > 1;
+					const bool general = !params_ok || (sq & (SUMQ_SEG_FLAG | SUMQ_LUT16_FLAG | SUMQ_SPAN0_FLAG)) || g.par.n_segs > 1;
 					if (!general) break;
-					if (hl == 0) g.left[atomicAdd(g.left_cnt, 1u)] = un;       // not for this kernel: hand the unit over
+					if (lane == 0) g.left[atomicAdd(g.left_cnt, 1u)] = un;     // not for this kernel: hand the unit over
 				}
-				if (!live) { u.pc = curbase; u.pend = curbase; break; }
+				if (!live) { u.pc = TW_SEL(hm, curb, u.pc); u.pend = TW_SEL(hm, curb, u.pend); break; }
 				c_base = un.start; c_rel0 = (int)(un.start - g.off[un.read]); c_room = un.len; c_read = un.read; c_tile0 = 0;
 				// LDS of the half for a new unit: marks never match, every XY slot fails the window test, the read's table (as bytes)
 				const uint2 *src = (const uint2*)(g.lut + (int64_t)c_read * g.lut_stride);
-				ulonglong2 an = make_ulonglong2(0, 0);
-				if (hl < c_room) an = g.a[c_base + hl];                        // the unit's first tile
+				uint64_t tl_x = 0, tl_y = 0;
+				if (lane < c_room) { const ulonglong2 t = g.a[c_base + lane]; tl_x = t.x; tl_y = t.y; }   // the unit's first tile
 				wave_mem_fence();
-				for (int k = hl; k * 4 <= g.par.bw; k += 32) {                 // lut_stride is a multiple of 8 entries: whole uint2 loads
+				for (int k = lane; k * 4 <= g.par.bw; k += 64) {               // lut_stride is a multiple of 8 entries: whole uint2 loads
 					const uint2 t = src[k];
 					const uint32_t w = (t.x & 0xffu) | (t.x >> 8 & 0xff00u) | (t.y << 16 & 0xff0000u) | (t.y << 8 & 0xff000000u);
-					tw_st32(c_lut + ((uint32_t)k << 2), (int)w);
+					tw_st32(lutb + ((uint32_t)k << 2), (int)w);
 				}
-				const uint32_t x_none = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)an.x, 32 * hs) - (uint32_t)maxx - 1u;   // "no anchor here" (x+1 encoding)
-				for (int k = hl; k < 128; k += 32) tw_st64(TW_XYS(k, hs), x_none, 0u);
-				for (int k = hl; k < 65; k += 32) tw_st32(mkbase + ((uint32_t)k << 2), -1);
+				const uint32_t x_none = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tl_x, 0) - (uint32_t)maxx - 1u;   // "no anchor here" (x+1 encoding)
+				for (int k = lane; k < 128; k += 64) tw_st64(((uint32_t)k << 4 | (uint32_t)hs << 3) + TW_XY, x_none, 0u);
+				for (int k = lane; k < 65; k += 64) tw_st32(mkb + ((uint32_t)k << 2), -1);
 				wave_mem_fence();
 				c_xcarry = 0;
-				u.slow = 0;
-				if (take_tile(an) > 0) goes_on = true;                         // (a unit has at least two anchors: always)
+				if (lane == 0) tw_st32(sa + TW_CARRY + 12u, 0);
+				if (take_tile(tl_x, tl_y) > 0) goes_on = true;                 // (a unit has at least two anchors: always)
 			}
 			TW_STAMP_A(if (g.stamp) st_unit += (unsigned int)(TW_NOW() - tu0);)
 			// ---- the tile's first anchor becomes current
 			if (live) {
 				const uint32_t i = (uint32_t)c_tile0;
-				u.maxj4 = -4; u.nskip = 0; u.kb4 = 0;
-				u.S = (i - 1u) << TW_SH | c_8h; u.m4 = ((i - 1u) << 2) + mkbase;
-			} else lane_retired = true;
-			if (hl == 0) {
-				tw_st128(sa, (uint32_t)c_next, (uint32_t)((uint64_t)c_next >> 32), (uint32_t)c_base, (uint32_t)((uint64_t)c_base >> 32));
-				tw_st128(sa + 16u, (uint32_t)c_xcarry, (uint32_t)(c_xcarry >> 32), (uint32_t)c_rel0, (uint32_t)c_room);
+				u.S = TW_SEL(hm, (i - 1u) << 4 | (uint32_t)hs << 3, u.S); u.m4 = TW_SEL(hm, ((i - 1u) << 2) + mkb, u.m4);
+			} else retired |= hm;
+			if (lane == 0) {
+				tw_st64(sa, (uint32_t)c_next, (uint32_t)((uint64_t)c_next >> 32)); tw_st64(sa + 8u, (uint32_t)c_base, (uint32_t)((uint64_t)c_base >> 32));
+				tw_st64(sa + 16u, (uint32_t)c_xcarry, (uint32_t)(c_xcarry >> 32)); tw_st64(sa + 24u, (uint32_t)c_rel0, (uint32_t)c_room);
 				tw_st64(sa + 32u, (uint32_t)c_read, (uint32_t)c_tile0);
 			}
 		}
 		wave_mem_fence();
-		live_m &= ~__builtin_amdgcn_ballot_w64(lane_retired);
+		live_m &= ~retired;
 		contm &= ~svc;
 	};
 
@@ -507,26 +502,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 		wave_mem_fence();
 		const tw_u32x2 cur = tw_ld64(a_cur);                                 // the running max just written
 		if (__builtin_amdgcn_inverse_ballot_w64(D)) {
-			u.maxj4 = -4; u.nskip = 0;
 			u.m4 += 4u;
-			u.S = ((u.m4 - c_mkbase) << (TW_SH - 2)) | c_8h; u.kb4 = 0;
-			u.pc += 16u;
+			u.S = ((u.m4 - c_mkbase) << 2) | c_8h;
+			u.pc += 8u;
 		} else {
-			u.nskip = vlast; u.maxj4 = (int)cur.x; u.maxf = (int)cur.y;
-			u.S -= 32u << TW_SH; u.kb4 = 128u;
-			++u.slow;
+			if (hl == 0) {                                                   // what the second chunk starts from
+				tw_st64(st_addr + TW_CARRY, cur.x, cur.y);
+				tw_st32(st_addr + TW_CARRY + 8u, vlast);
+				tw_st32(st_addr + TW_CARRY + 12u, tw_ld32(st_addr + TW_CARRY + 12u) + 1);
+			}
+			u.S -= 512u;
 		}
 		contm = ~D & ~giveup & live_m;
 		if (__builtin_expect(giveup != 0, 0)) {
 			if (__builtin_amdgcn_inverse_ballot_w64(giveup)) {
 				wave_mem_fence();
 				if (hl == 0) {
-					TwinCold c = TW_COLD;
+					const TwinCold c = TW_COLD;
 					Unit un; un.start = c.base; un.read = c.read; un.len = c.room;
-					g.left[atomicAdd(g.left_cnt, 1u)] = un;
-					c.room = 0; TW_COLD = c;                                 // the unit is over for this kernel
+					g.left[atomicAdd(g.left_cnt, 1u)] = un;                  // the unit is over for this kernel: an empty tile ...
 				}
-				u.pc = curbase; u.pend = curbase; u.kb4 = 0;                 // nothing to flush; service() picks the half's next unit
+				u.pc = curbase; u.pend = curbase;                            // ... has nothing to flush and cannot go on: service() picks the half's next unit
 			}
 			return giveup;
 		}
@@ -549,9 +545,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 			uint32_t a_cur;
 			for (;;) {
 				const uint32_t t0 = u.S - L16;                               // lane k <-> predecessor j = jtop - k of its half's anchor
-				const tw_u32x2 xy = tw_ld64(TW_XYA(t0));
-				const tw_u32x2 pf = tw_ld64(TW_PFA(t0));
-				const tw_u32x4 cur = tw_ld128(u.pc);                         // the anchor itself: x, q, q_span - 1, q_span
+				const tw_u32x2 xy = tw_ld64((t0 & 0x7f8u) + TW_XY);
+				const tw_u32x2 pf = tw_ld64((t0 & 0x3f8u) + TW_PF);
+				const tw_u32x2 cur = tw_ld64(u.pc);                          // the anchor itself: x, q
+				const int spm1 = tw_ld_u8((u.pc >> 3) + TW_SP_OF_XQ);        // ... and q_span - 1
 				const uint32_t drm1 = cur.x - xy.x, dqm1 = cur.y - xy.y;     // the ring holds x + 1, q + 1: differences minus one
 				const uint32_t ddl = tw_sad(drm1, dqm1, c_lut);              // |dr - dq| + the half's table base
 				const uint32_t dqs = SAMEGAP ? dqm1 : __builtin_elementwise_add_sat(dqm1, c_dqoff);
@@ -559,25 +556,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				const uint64_t okm = TW_ULT(m3, c_M);                        // chain.c:252-260 as one compare
 				// the mark round trip (chain.c:281: store by distance, the others to the sink; then the lane's own word) and the table
 				// lookup are issued back to back, before anything waits for either
-#ifdef TW_EXP_EXECMARK
-				if (__builtin_amdgcn_inverse_ballot_w64(okm)) tw_st32(min(u.m4 - pf.x, c_far), (int)u.m4);
-#else
 				const uint32_t dst = TW_SEL(okm, min(u.m4 - pf.x, c_far), c_far);
 				tw_st32(dst, (int)u.m4);
-#endif
 				wave_mem_fence();
 				const int tj = tw_ld32(c_own);
-#ifdef TW_EXP_NOCLAMP
-				const int lutv = tw_ld_i8(ddl);                              // lanes that fail the filters read anything (out of range: 0); masked below
-#else
 				const int lutv = tw_ld_i8(min(ddl, c_bwl));
-#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 				__builtin_amdgcn_sched_barrier(0);
 #endif
-				const int sc0 = min(min((int)dqm1, (int)drm1), (int)cur.z);  // chain.c:262-263, minus one
-				const int sc = TW_SEL(okm, sc0 + (int)pf.y + lutv, c_min);   // chain.c:272-273 via the table
-				const int excl = max(tw_excl_max32(sc), (int)cur.w);
+				const int sc0 = min(min((int)dqm1, (int)drm1), spm1);        // chain.c:262-263, minus one
+				const int sc = TW_SEL(okm, sc0 + (int)pf.y + lutv, c_min);   // chain.c:272-273 via the table, minus one (the ring holds f - 1)
+				const int excl = max(tw_excl_max32(sc), spm1);               // (q_span - 1 >= 0: the scan's zero fill stays below it)
 				const uint64_t A = TW_SGT(sc, excl);                         // new running max (chain.c:274); masked lanes hold INT_MIN
 				B = TW_EQ(tj, u.m4) & okm & ~A;                              // marked and not better (chain.c:277)
 				const uint64_t OUT = TW_SGE(drm1, c_Mout);                   // the half's last lane is outside the window (or no anchor there yet)
@@ -588,19 +577,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				tile = 0; X = 0; a_cur = 0;
 				if (__builtin_expect((TW_SGT(cB, 0) & A) != 0, 0)) { force_general = true; break; }
 				// the running max goes to PF[i]: the half's last A lane writes its own score and predecessor, or (none) the half's
-				// lane 0 writes "no predecessor, q_span"
-				const uint32_t S1 = u.S + (1u << TW_SH);
-				a_cur = TW_PFA(S1) - TW_PF;                                  // PF slot of anchor i (S = 16 (i - 1) + 8h in the first chunk)
+				// lane 0 writes "no predecessor, q_span" (minus one)
+				const uint32_t S1 = u.S + 16u;
+				a_cur = S1 & 0x3f8u;                                         // PF slot of anchor i (S = 16 (i - 1) + 8h in the first chunk)
 				{
 					const uint32_t wp = TW_SEL(A, u.m4 - c_own, 0xfffffffcu);      // 4 j of the lane's predecessor: 4 (i - 1 - k)
-					const int wf = TW_SEL(A, sc, (int)cur.w);
+					const int wf = TW_SEL(A, sc, spm1);
 					if (__builtin_amdgcn_inverse_ballot_w64(tw_last_or_lane0(A))) tw_st64(a_cur + TW_PF, wp, (uint32_t)wf);
 				}
 				// scan complete: break taken, or the half's last lane is outside the window (x is sorted: nothing older can matter)
 				X = (TW_SGE(cB, c_ms) & B) | OUT;
 				if (__builtin_expect(tw_both_halves(X) == 0, 0)) break;
 				u.m4 += 4u; u.S = S1;
-				u.pc += 16u;
+				u.pc += 8u;
 				tile = TW_SGE(u.pc, u.pend);
 				TW_STAMP(if (g.stamp) ++st_n_fast;)
 				if (__builtin_expect(tile != 0, 0)) break;
@@ -614,25 +603,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 			// ------------------------------------------------------------ general pass: second chunks, idle halves, interleaved walks
 			force_general = false;
 			const uint32_t t0 = u.S - L16;
-			const tw_u32x2 xy = tw_ld64(TW_XYA(t0));
-			const tw_u32x2 pf = tw_ld64(TW_PFA(t0));
-			const tw_u32x4 cur = tw_ld128(u.pc);
+			const tw_u32x2 xy = tw_ld64((t0 & 0x7f8u) + TW_XY);
+			const tw_u32x2 pf = tw_ld64((t0 & 0x3f8u) + TW_PF);
+			const tw_u32x2 cur = tw_ld64(u.pc);
+			const int spm1 = tw_ld_u8((u.pc >> 3) + TW_SP_OF_XQ);
 			const uint64_t first = ~contm;                                       // halves in their first chunk: running max = q_span, nothing carried
-			const int maxf = TW_SEL(first, (int)cur.w, u.maxf);
-			const uint32_t maxj4 = TW_SEL(first, 0xfffffffcu, (uint32_t)u.maxj4);
-			const int nskip0 = TW_SEL(first, 0, u.nskip);
+			const tw_u32x2 carry = tw_ld64(st_addr + TW_CARRY);
+			const int maxf = TW_SEL(first, spm1, (int)carry.y);
+			const uint32_t maxj4 = TW_SEL(first, 0xfffffffcu, carry.x);
+			const int nskip0 = TW_SEL(first, 0, tw_ld32(st_addr + TW_CARRY + 8u));
+			const uint32_t kb4 = TW_SEL(first, 0u, 128u);                        // 128 * c
 			const uint32_t drm1 = cur.x - xy.x, dqm1 = cur.y - xy.y;
 			const uint32_t ddl = tw_sad(drm1, dqm1, c_lut);
 			const uint32_t dqs = SAMEGAP ? dqm1 : __builtin_elementwise_add_sat(dqm1, c_dqoff);
 			const uint32_t m3 = max(max(drm1, dqs), ddl + c_cbwl);
 			// not evaluated: lane 31 of a second chunk (j = i - 64 shares its PF slot with anchor i itself) and idle halves
 			const uint64_t okm = TW_ULT(m3, c_M) & ~(contm & TW_HI31) & live_m;
-			const int sc0 = min(min((int)dqm1, (int)drm1), (int)cur.z);
+			const int sc0 = min(min((int)dqm1, (int)drm1), spm1);
 			const int lutv = tw_ld_i8(min(ddl, c_bwl));
 			const uint32_t dst = TW_SEL(okm, min(u.m4 - pf.x, c_far), c_far);
 			tw_st32(dst, (int)u.m4);
 			wave_mem_fence();
-			const int tj = tw_ld32(c_own + u.kb4);
+			const int tj = tw_ld32(c_own + kb4);
 			const int sc = TW_SEL(okm, sc0 + (int)pf.y + lutv, c_min);
 			const int excl = max(tw_excl_max32(sc), maxf);
 			const uint64_t A = TW_SGT(sc, excl);
@@ -654,9 +646,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				brk = TW_SGT(nskip_after, c_ms) & B;
 				Ap = tw_below_first(A, brk);
 			}
-			const uint32_t a_cur = TW_PFA((((u.m4 - c_mkbase) + 4u) << (TW_SH - 2)) | c_8h);   // PF slot of anchor i (m4 = 4 (i - 1) + mark base)
+			const uint32_t a_cur = (((((u.m4 - c_mkbase) + 4u) << 2) & 0x3f8u) | c_8h) + TW_PF;   // PF slot of anchor i (m4 = 4 (i - 1) + mark base)
 			{
-				const uint32_t wp = TW_SEL(Ap, u.m4 - c_own - u.kb4, maxj4);          // 4 j = 4 (i - 1 - 32 c - k)
+				const uint32_t wp = TW_SEL(Ap, u.m4 - c_own - kb4, maxj4);          // 4 j = 4 (i - 1 - 32 c - k)
 				const int wf = TW_SEL(Ap, sc, maxf);
 				if (__builtin_amdgcn_inverse_ballot_w64(tw_last_or_lane0(Ap))) tw_st64(a_cur, wp, (uint32_t)wf);
 			}
@@ -704,14 +696,16 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
 	// diagnostic: CHAINDP_TWIN_STAMP=1 makes the kernel stamp where its waves' time goes (s_memtime: shader-clock ticks) and this
 	// function print the averages -- it synchronises, so never set it in a timed run
 	static unsigned long long *d_stamp = nullptr;
-	static const bool stamp = getenv("CHAINDP_TWIN_STAMP") != nullptr;           // (read once: not on the launch path)
+	const bool stamp = getenv("CHAINDP_TWIN_STAMP") != nullptr;
 	if (stamp && !d_stamp && hipMalloc((void**)&d_stamp, (size_t)cap * 96) != hipSuccess) d_stamp = nullptr;
 	g.stamp = stamp ? d_stamp : nullptr;
 	if (g.stamp) (void)hipMemsetAsync(d_stamp, 0, (size_t)blocks * 96, st);
 	{
+		hipFuncAttributes fa;                                        // LDS is addressed by raw byte offsets from 0: no static LDS may sit in front
 		const void *fn = par.max_dist_y >= par.max_dist_x ? (const void*)k_chain_twin<true> : (const void*)k_chain_twin<false>;
-		const hipError_t e = check_no_static_lds(fn);        // LDS is addressed by raw byte offsets from 0
+		const hipError_t e = hipFuncGetAttributes(&fa, fn);
 		if (e != hipSuccess) return e;
+		if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
 	}
 	if (par.max_dist_y >= par.max_dist_x) hipLaunchKernelGGL(k_chain_twin<true>, dim3((unsigned)blocks), dim3(64), TW_LDS_BYTES, st, g);
 	else hipLaunchKernelGGL(k_chain_twin<false>, dim3((unsigned)blocks), dim3(64), TW_LDS_BYTES, st, g);

@@ -96,6 +96,8 @@ __device__ __forceinline__ void wave_global_fence()
 // non-zero segment id", which sends the read's units to the general variant of the DP kernel.
 #define SUMQ_SEG_FLAG (1ull << 63)
 #define SUMQ_LUT16_FLAG (1ull << 62)   // the read's table of 1 - cost does not fit int8 (set by k_build_lut; k_chain_twin hands such reads over)
+#define SUMQ_SPAN0_FLAG (1ull << 61)   // some anchor of the read has q_span 0 (k_chain_twin keeps scores minus one with a floor of 0: it hands such reads over)
+#define SUMQ_FLAGS (SUMQ_SEG_FLAG | SUMQ_LUT16_FLAG | SUMQ_SPAN0_FLAG)
 
 __device__ __forceinline__ int span_of_hi(uint32_t yhi) { return (int)(yhi & 0xffu); }        // (y>>32)&0xff
 __device__ __forceinline__ int seg_of_hi(uint32_t yhi) { return (int)((yhi >> 16) & 0xffu); } // (y>>48)&0xff

@@ -125,7 +125,8 @@ struct GpuShare {
 
 struct Service {
 	bool up = false;
-	int n_gpus_cfg = 0, max_packets = 8192, services_per_gpu = 2;
+	int n_gpus_cfg = 0, n_groups_cfg = 0, max_packets = 8192, services_per_gpu = 2;
+	std::vector<int> group_device;               // service group -> GPU (one group per GPU unless chaindp_fpga_configure_groups says otherwise)
 	int64_t cap_anchors = 32ll << 20, cap_reads = 1 << 19;   // device batch capacity per context (512 MiB of anchors)
 	unsigned long max_inflight = 1ul << 30;
 	// fpga_set_params (main.c:243)
@@ -178,12 +179,13 @@ void seal_index_locked()
 	}
 }
 
-void service_loop(int device)
+void service_loop(int group)
 {
+	const int device = g.group_device[(size_t)group];
 	const int64_t cap_anchors = g.cap_anchors, cap_reads = g.cap_reads;
 	chaindp_ctx_t *ctx = chaindp_create(device, cap_anchors, cap_reads);
 	if (!ctx) { fprintf(stderr, "[chaindp-fpga] %s\n", chaindp_last_error(nullptr)); fail_hard("cannot create a device context"); }
-	GpuShare &share = *g.gpus[(size_t)device];
+	GpuShare &share = *g.gpus[(size_t)group];
 	std::vector<Submitted> pk;
 	std::vector<ReadRef> reads;
 	for (;;) {
@@ -468,6 +470,12 @@ extern "C" void chaindp_fpga_configure(int n_gpus, int max_packets_per_batch, un
 	if (max_inflight_bytes > 0) g.max_inflight = max_inflight_bytes;
 }
 
+extern "C" void chaindp_fpga_configure_groups(int n_groups)
+{
+	std::lock_guard<std::mutex> lk(g.mu);
+	g.n_groups_cfg = n_groups > 0 ? n_groups : 0;
+}
+
 extern "C" void chaindp_fpga_configure_capacity(int64_t max_anchors_per_batch, int64_t max_reads_per_batch)
 {
 	std::lock_guard<std::mutex> lk(g.mu);
@@ -502,12 +510,15 @@ extern "C" int fpga_init(int flag)
 	if (g.n_gpus_cfg > 0 && g.n_gpus_cfg < n) n = g.n_gpus_cfg;
 	g.stopping = false; g.exit_block = false; g.warned_capacity = false;
 	for (int k = 0; k < 5; ++k) g.stats[k] = 0;
-	g.gpus.clear();
-	for (int d = 0; d < n; ++d) g.gpus.emplace_back(new GpuShare());
+	// service groups: one per GPU; chaindp_fpga_configure_groups can ask for more than there are GPUs, group k then runs on GPU k mod n
+	// with contexts, index copy and counters of its own (how the multi-GPU dispatch is rehearsed on a one-GPU box)
+	const int groups = g.n_groups_cfg > 0 ? g.n_groups_cfg : n;
+	g.gpus.clear(); g.group_device.clear();
+	for (int k = 0; k < groups; ++k) { g.gpus.emplace_back(new GpuShare()); g.group_device.push_back(k % n); }
 	// two service threads (two contexts, two streams) per GPU: while one batch is in its kernels the other one's
 	// packets cross PCIe, in either direction.  Every thread takes work when it is free, so a GPU that is busy takes none:
 	// the GPUs of a node share the packet stream by the work they get done (chaindp_fpga_stats_gpu shows the split).
-	for (int d = 0; d < n; ++d) for (int k = 0; k < g.services_per_gpu; ++k) g.workers.emplace_back(service_loop, d);
+	for (int d = 0; d < groups; ++d) for (int k = 0; k < g.services_per_gpu; ++k) g.workers.emplace_back(service_loop, d);
 	g.up = true;
 	return 0;
 }

@@ -15,7 +15,8 @@ from .chaindp import SEED_DTYPE
 PKT_MINIMIZERS = 3        # the reference's task packets (map.c:302)
 PKT_ANCHORS = 0x41        # this build's: payload = the read's sorted anchors
 
-SHIM_EXTRA_SYMBOLS = ("chaindp_fpga_configure", "chaindp_fpga_configure_capacity", "chaindp_fpga_stats", "chaindp_fpga_stats_gpu")
+SHIM_EXTRA_SYMBOLS = ("chaindp_fpga_configure", "chaindp_fpga_configure_capacity", "chaindp_fpga_configure_groups", "chaindp_fpga_stats",
+                      "chaindp_fpga_stats_gpu")
 
 DRIVER_SYMBOLS = (
     "fpga_init", "fpga_finalize", "fpga_get_retbuf", "fpga_release_retbuf", "fpga_get_writebuf",
@@ -78,6 +79,8 @@ def lib():
         L.chaindp_fpga_stats.argtypes = [vp]
         L.chaindp_fpga_configure_capacity.restype = None
         L.chaindp_fpga_configure_capacity.argtypes = [C.c_int64, C.c_int64]
+        L.chaindp_fpga_configure_groups.restype = None
+        L.chaindp_fpga_configure_groups.argtypes = [C.c_int]
         L.chaindp_fpga_stats_gpu.restype = C.c_int
         L.chaindp_fpga_stats_gpu.argtypes = [C.c_int, vp]
         _lib = L
@@ -177,9 +180,10 @@ class Driver:
     recv_task_thread (fpga_chaindp.c:228-270): blocks in fpga_get_retbuf, copies the packet, releases it."""
 
     def __init__(self, bw=500, is_cdna=0, max_skip=25, min_sc=40, n_gpus=0, max_packets_per_batch=64, flag=0, max_occ=0, index=None,
-                 max_anchors_per_batch=32 << 20, max_reads_per_batch=1 << 19):
+                 max_anchors_per_batch=32 << 20, max_reads_per_batch=1 << 19, n_groups=0):
         self.L = lib()
         self.L.chaindp_fpga_configure(n_gpus, max_packets_per_batch, 0)
+        self.L.chaindp_fpga_configure_groups(n_groups)                     # 0: one service group per GPU
         self.L.chaindp_fpga_configure_capacity(max_anchors_per_batch, max_reads_per_batch)
         if self.L.fpga_init(0) != 0:
             raise chaindp.ChainDPError("fpga_init failed: no GPU (there is no CPU fallback)")

@@ -1,8 +1,11 @@
 """Read sharding across the GPUs of one node and the (only) collective steps of a multi-GPU run.
 
-Reads are independent DP problems, so a job is partitioned, not exchanged: rank r of W owns reads
-[r*reads_per_gpu, (r+1)*reads_per_gpu) of the seeded job (weak scaling: per-GPU work is fixed).  The
-only communication is the benchmark's barrier and two scalar reductions (max time, sum of anchors),
+Reads are independent DP problems, so a job is partitioned, not exchanged.  Two ways to deal a seeded job:
+  strong scaling (bench.py's default: BASELINE configs[3] is ONE job of 100,000 reads "read-sharded across 8"):
+    generate_job_shard() -- the job is fixed, rank r of W takes the reads between the points where the cumulative
+    ANCHOR count crosses r/W and (r+1)/W of the job's total, so per-GPU work shrinks as W grows;
+  weak scaling: generate_shard() -- rank r owns reads [r*reads_per_gpu, (r+1)*reads_per_gpu), per-GPU work is fixed.
+The only communication is the benchmark's barrier and two scalar reductions (max time, sum of anchors),
 done with torch.distributed on whatever backend the process group uses (nccl = RCCL on the GPU box,
 gloo in the CPU tests).
 """
@@ -36,6 +39,24 @@ def generate_shard(preset, rank, world, reads_per_gpu, seed, threads=None, balan
     else:
         raise ValueError("balance must be 'reads' or 'anchors'")
     return anchorgen.generate(preset, n_reads=n, seed=seed, first_read=first, threads=threads, **overrides)
+
+
+def job_cuts(preset, world, job_reads, seed, threads=None, **overrides):
+    """Read indices (len world+1) at which the seeded job of `job_reads` reads is cut for `world` ranks: every rank derives the
+    same cuts from the job's offsets alone (no anchors generated, nothing exchanged)."""
+    return split_by_anchors(anchorgen.offsets(preset, n_reads=job_reads, seed=seed, threads=threads, **overrides), world)
+
+
+def generate_job_shard(preset, rank, world, job_reads, seed, threads=None, **overrides):
+    """Strong scaling: rank `rank`'s share of the FIXED seeded job of `job_reads` reads, cut by anchor count.
+    Returns (off, anchors, first_read): the shard's CSR offsets (starting at 0), its anchors, and the job-wide index of
+    its first read."""
+    if not (0 <= rank < world):
+        raise ValueError("rank outside world")
+    cuts = job_cuts(preset, world, job_reads, seed, threads=threads, **overrides)
+    first, n = int(cuts[rank]), int(cuts[rank + 1] - cuts[rank])
+    off, a = anchorgen.generate(preset, n_reads=n, seed=seed, first_read=first, threads=threads, **overrides)
+    return off, a, first
 
 
 def split_by_anchors(off, parts):

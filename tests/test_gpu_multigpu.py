@@ -14,15 +14,14 @@ from minimap2_chaindp_amd import anchorgen as ag, chaindp, fpga, params as P
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.skipif(chaindp.device_count() < 2, reason="needs at least two GPUs")
-def test_packet_stream_is_shared_by_all_gpus_and_bit_exact():
-    n_gpus = chaindp.device_count()
+def _stream_and_check(n_groups_cfg, n_expected, fair_split=True):
+    n_gpus = n_expected
     par = P.preset("ava-ont")
     n_reads, per_packet, n_threads = 400 * n_gpus, 8, 8
     off, a = ag.generate("ava-ont", n_reads=n_reads, seed=4242)
     reads = [(r, a[off[r]:off[r + 1]]) for r in range(n_reads)]
     packets = [reads[k:k + per_packet] for k in range(0, n_reads, per_packet)]
-    with fpga.Driver(bw=par.bw, is_cdna=par.is_cdna, max_skip=par.max_skip, min_sc=par.min_sc, max_packets_per_batch=4) as drv:
+    with fpga.Driver(bw=par.bw, is_cdna=par.is_cdna, max_skip=par.max_skip, min_sc=par.min_sc, max_packets_per_batch=4, n_groups=n_groups_cfg) as drv:
         def producer(tid):
             for k in range(tid, len(packets), n_threads):
                 assert drv.submit(fpga.build_task_packet(packets[k], gap_ref=par.max_dist_x, gap_qry=par.max_dist_y, tid=tid), tid) == 0
@@ -34,7 +33,9 @@ def test_packet_stream_is_shared_by_all_gpus_and_bit_exact():
         st = drv.stats()
     assert len(per_gpu) == n_gpus and st["anchors"] == int(off[-1]) and sum(x[1] for x in per_gpu) == int(off[-1])
     fair = int(off[-1]) / n_gpus
-    assert all(abs(x[1] - fair) <= fair / 3 for x in per_gpu), per_gpu
+    assert all(x[0] > 0 and x[1] > 0 for x in per_gpu), per_gpu                      # every GPU (group) took part
+    if fair_split:
+        assert all(abs(x[1] - fair) <= fair / 3 for x in per_gpu), per_gpu
     seen = {}
     for raw in results:
         for read_id, err, seeds in fpga.parse_result_packet(raw):
@@ -44,6 +45,17 @@ def test_packet_stream_is_shared_by_all_gpus_and_bit_exact():
         ar = np.ascontiguousarray(a[off[r]:off[r + 1]])
         f, p, v, _ = ol.oracle_fpv(par, ar)
         assert seen[r].tobytes() == ol.oracle_compact(par, ar, f, p, v).tobytes(), r
+
+
+@pytest.mark.skipif(chaindp.device_count() < 2, reason="needs at least two GPUs")
+def test_packet_stream_is_shared_by_all_gpus_and_bit_exact():
+    _stream_and_check(0, chaindp.device_count())
+
+
+def test_two_service_groups_share_one_packet_stream_on_any_box():
+    """The shim's multi-GPU dispatch with two service groups (each with its own two contexts and counters), on however many GPUs the
+    box has -- on a one-GPU box both groups run on GPU 0: same packets, same checks as the multi-GPU test."""
+    _stream_and_check(2, 2, fair_split=chaindp.device_count() >= 2)      # (two groups on one GPU take turns as the scheduler lets them)
 
 
 @pytest.mark.skipif(chaindp.device_count() < 2, reason="needs at least two GPUs")

@@ -53,6 +53,49 @@ def test_two_ranks_deal_the_skewed_job_by_anchor_count():
     assert abs(a0 - a1) <= int(np.diff(off).max())                       # within one (largest) read of even, whatever the read counts
 
 
+def _worker_strong(rank, world, port, q):
+    """bench.py's default (--scaling strong): ONE fixed job cut over the ranks by anchor count (shard.generate_job_shard), the oracle
+    as the compute leg, then the two reductions."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import oracle_lib as ol
+    from minimap2_chaindp_amd import params, shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    off, a, first = shard.generate_job_shard("ava-ont", rank, world, 2 * READS, SEED, threads=1)
+    f, p, v, _ = ol.oracle_batch(params.preset("ava-ont"), off, a, threads=1)
+    chk = int(np.bitwise_xor.reduce(f.astype(np.int64) * 31 + p))
+    dist.barrier()
+    t_max, n_all = shard.reduce_job(1.0 + rank, int(off[-1]), dist)
+    q.put((rank, first, len(off) - 1, int(off[-1]), chk, t_max, n_all))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_cut_one_fixed_job_by_anchor_count():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_strong, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=180) for _ in procs)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from minimap2_chaindp_amd import anchorgen, params, shard
+    off, a = anchorgen.generate("ava-ont", n_reads=2 * READS, seed=SEED, threads=2)
+    f, p, v, _ = ol.oracle_batch(params.preset("ava-ont"), off, a, threads=2)
+    cuts = shard.split_by_anchors(off, 2)
+    assert [r[1] for r in res] == [int(cuts[0]), int(cuts[1])] and sum(r[2] for r in res) == 2 * READS      # the shards tile the job
+    for rank, first, n_reads, n, chk, t_max, n_all in res:
+        lo, hi = int(off[first]), int(off[first + n_reads])
+        assert n == hi - lo and chk == int(np.bitwise_xor.reduce(f[lo:hi].astype(np.int64) * 31 + p[lo:hi]))   # same reads, same results
+        assert t_max == 2.0 and n_all == int(off[-1])                                                     # max over ranks, sum over ranks
+    assert abs(res[0][3] - res[1][3]) <= int(np.diff(off).max())                                          # near-equal anchor counts
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -27,7 +27,7 @@ short = lambda n: n.split("(")[0].replace("void ", "").replace("chaindp::", "")
 print(f"# profile summary of {os.path.basename(d)}")
 try:
     b = json.loads(open(os.path.join(d, "bench_under_trace.json")).read().strip().splitlines()[-1])
-    anchors = b["config"]["anchors_per_gpu"]
+    anchors = b["config"].get("anchors_on_rank0") or b["config"]["anchors_per_gpu"]
     print(f"bench under trace: value={b['value']:.4g} anchors/s, kernel_ms={b['kernel_ms']}, anchors/launch={anchors}")
 except Exception as e:  # noqa: BLE001
     anchors = None

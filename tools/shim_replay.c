@@ -1,10 +1,12 @@
 /*
  * shim_replay.c -- a C host that replays a file of ready-made task packets through the reference's driver ABI
  * (fpga.h:37-62), the way the reference's threads do (map.c:439-444 producers, fpga_chaindp.c:228-270 receiver),
- * after streaming an index image with fpga_load_index (main.c:201-204).  Used for the reference's own minimizer
- * packets (type 3): tools/shim_minimizer_bench.py --write-replay makes the file from a seed dump.  Prints the
- * PCIe-inclusive anchors/s (anchors = new_seed candidates the device collected: sum of seed counts is reported too).
- *   gcc -O2 -o tools/shim_replay tools/shim_replay.c -Iinclude -Lminimap2_chaindp_amd/csrc -lchaindp_hip -lpthread
+ * after streaming an index image with fpga_load_index (main.c:201-204; empty blobs for anchor packets).  Both packet
+ * kinds: the reference's own minimizer packets (type 3: tools/shim_minimizer_bench.py --write-replay, bench.py) and this
+ * build's anchor packets (type 0x41).  Prints one JSON line per round (PCIe-inclusive seconds, payload elements in,
+ * new_seed records out) and a last one with the shim's batch counts and per-GPU shares.
+ *   make -C minimap2_chaindp_amd/csrc shim_replay          (bench.py's packet_abi entry runs it)
+ *   shim_replay <file> [producers=8] [reps=4] [rounds=3] [max_packets_per_batch=256] [n_gpus=0 (all)]
  * File: "SHIMRPL1", int32 flag, mid_occ, bw, max_skip, min_sc, n_packets; 4 x (int64 bytes, blob); n_packets x (uint32 size, packet).
  */
 #include <pthread.h>
@@ -58,16 +60,17 @@ static void *receiver(void *arg)
 
 int main(int argc, char **argv)
 {
-	if (argc < 2) { fprintf(stderr, "usage: shim_replay <file> [producers=8] [reps=4] [rounds=3]\n"); return 2; }
+	if (argc < 2) { fprintf(stderr, "usage: shim_replay <file> [producers=8] [reps=4] [rounds=3] [max_packets_per_batch=256] [n_gpus=0]\n"); return 2; }
 	n_prod = argc > 2 ? atoi(argv[2]) : 8;
 	reps = argc > 3 ? atoi(argv[3]) : 4;
 	int rounds = argc > 4 ? atoi(argv[4]) : 3, k, round;
+	const int max_pk = argc > 5 ? atoi(argv[5]) : 256, n_gpus = argc > 6 ? atoi(argv[6]) : 0;
 	FILE *fp = fopen(argv[1], "rb");
 	char magic[8];
 	int32_t hdr[6];
 	if (!fp || fread(magic, 1, 8, fp) != 8 || memcmp(magic, "SHIMRPL1", 8) || fread(hdr, 4, 6, fp) != 6) { fprintf(stderr, "bad replay file\n"); return 1; }
 	n_packets = hdr[5];
-	chaindp_fpga_configure(0, 256, 0);
+	chaindp_fpga_configure(n_gpus, max_pk, 0);
 	if (fpga_init(0) != 0) return 1;                                                                 /* main.c:512 */
 	for (k = 0; k < 4; ++k) {
 		int64_t nb;
@@ -80,12 +83,23 @@ int main(int argc, char **argv)
 	}
 	fpga_set_params(hdr[2], 0, hdr[3], hdr[4], hdr[0], hdr[1]);                                      /* main.c:243 */
 	pkt = (char**)malloc(sizeof(char*) * n_packets); pkt_size = (uint32_t*)malloc(4 * n_packets);
-	int64_t minimizers = 0;
+	int64_t elements = 0, reads = 0, bytes = 0;
+	int type = 0;
 	for (k = 0; k < n_packets; ++k) {
 		if (fread(&pkt_size[k], 4, 1, fp) != 1) return 1;
 		pkt[k] = (char*)malloc(pkt_size[k]);
 		if (fread(pkt[k], 1, pkt_size[k], fp) != pkt_size[k]) return 1;
-		minimizers += (pkt_size[k] - 64) / 16;
+		const chaindp_pkt_hdr_t *h = (const chaindp_pkt_hdr_t*)pkt[k];
+		const char *q = pkt[k] + sizeof(*h);
+		int i;
+		type = h->type;
+		for (i = 0; i < (int)h->num; ++i) {                                                          /* the walk of map.c:484-568 */
+			const chaindp_pkt_task_t *t = (const chaindp_pkt_task_t*)q;
+			const int64_t n = t->seednum > 0 ? t->seednum : 0;
+			elements += n; ++reads;
+			q += sizeof(*t) + CHAINDP_ALIGN64((uint64_t)n * sizeof(chaindp_anchor_t));
+		}
+		bytes += pkt_size[k];
 	}
 	fclose(fp);
 	pthread_t rx, *tx = (pthread_t*)malloc(sizeof(pthread_t) * n_prod);
@@ -95,12 +109,23 @@ int main(int argc, char **argv)
 		double t0 = now();
 		for (k = 0; k < n_prod; ++k) pthread_create(&tx[k], 0, producer, (void*)(intptr_t)k);
 		for (k = 0; k < n_prod; ++k) pthread_join(tx[k], 0);
-		while (got_packets < want) usleep(200);
+		while (got_packets < want) usleep(100);
 		double dt = now() - t0;
-		printf("round %d: %d packets x %d, ~%.1f M minimizers -> %lld new_seed records in %.1f ms: %.1f M records/s, %.1f M minimizers/s (err reads so far %lld)\n",
-		       round, n_packets, reps, minimizers * reps / 1e6, (long long)(got_seeds - seeds0), dt * 1e3, (got_seeds - seeds0) / dt / 1e6,
-		       minimizers * reps / dt / 1e6, (long long)got_err);
+		printf("{\"round\": %d, \"packet_type\": %d, \"producers\": %d, \"packets\": %lld, \"reads\": %lld, \"elements_in\": %lld, \"bytes_in\": %lld, "
+		       "\"records_out\": %lld, \"seconds\": %.6f, \"err_reads_so_far\": %lld}\n",
+		       round, type, n_prod, (long long)n_packets * reps, (long long)reads * reps, (long long)elements * reps, (long long)bytes * reps,
+		       (long long)(got_seeds - seeds0), dt, (long long)got_err);
 		fflush(stdout);
+	}
+	{
+		int64_t st[5], sg[2];
+		int ng, d;
+		chaindp_fpga_stats(st);
+		ng = chaindp_fpga_stats_gpu(0, sg);
+		printf("{\"shim\": {\"packets\": %lld, \"reads\": %lld, \"anchors\": %lld, \"device_batches\": %lld, \"err_reads\": %lld, \"gpus\": [",
+		       (long long)st[0], (long long)st[1], (long long)st[2], (long long)st[3], (long long)st[4]);
+		for (d = 0; d < ng; ++d) { chaindp_fpga_stats_gpu(d, sg); printf("%s{\"gpu\": %d, \"batches\": %lld, \"anchors\": %lld}", d ? ", " : "", d, (long long)sg[0], (long long)sg[1]); }
+		printf("]}}\n");
 	}
 	fpga_exit_block();                                                                               /* main.c:608 */
 	pthread_join(rx, 0);
