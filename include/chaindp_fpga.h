@@ -106,6 +106,9 @@ void chaindp_fpga_configure(int n_gpus, int max_packets_per_batch, unsigned long
  * service contexts, index copy and counters of its own: the node-level dispatch (a packet stream shared by several groups) can be
  * exercised on a box with one GPU.  0 = default. */
 void chaindp_fpga_configure_groups(int n_groups);
+/* Service contexts (host thread + device context + stream) per group, before fpga_init; default 2, at most 8.  While one context's
+ * batch is in its kernels, the others' packets cross PCIe. */
+void chaindp_fpga_configure_services(int contexts_per_group);
 /* Capacity of one device batch (per service context; defaults 32 Mi anchors, 512 Ki reads), before fpga_init.  A read
  * with more anchors than that -- or, for minimizer packets, more seeds -- is answered with err_flag = 1 (map.c:933-944); a
  * batch whose seeds do not fit is split and retried. */

@@ -36,6 +36,7 @@ struct chaindp_ctx {
 	uint32_t epoch = 0;
 	unsigned long long *d_sumq = nullptr;
 	Unit *d_units = nullptr;
+	chaindp::UnitAux *d_unit_aux = nullptr;   // per unit, beside d_units: what k_chain_twin needs to pick it up without further loads
 	Unit *d_left = nullptr;               // units the two-per-wave kernel hands over to k_chain_units
 	unsigned long long *d_left_cnt = nullptr;   // [0] handed-over count | the twin kernel's queue << 32; [1] count of d_deep; [2] k_chain_dense1's two queues
 	Unit *d_deep = nullptr;               // units k_chain_units hands over to its k_chain_dense (scans that keep reaching past the ring)
@@ -135,7 +136,7 @@ extern "C" void chaindp_destroy(chaindp_ctx_t *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	for (auto &es : ctx->pending) for (int k = 0; k < es.n; ++k) (void)hipEventDestroy(es.e[k]);
 	void *bufs[] = {ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_sumq, ctx->d_units,
-	                ctx->d_counters, ctx->d_left, ctx->d_left_cnt, ctx->d_deep, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->pre.units_tmp, ctx->pre.hist, ctx->pre.block_reads, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->cmp.sub, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
+	                ctx->d_counters, ctx->d_unit_aux, ctx->d_left, ctx->d_left_cnt, ctx->d_deep, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->pre.units_tmp, ctx->pre.hist, ctx->pre.block_reads, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->cmp.sub, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
 	for (void *b : bufs) if (b) (void)hipFree(b);
 	for (void *b : ctx->bot_allocs) if (b) (void)hipFree(b);
 	void *sbufs[] = {ctx->seed.kept, ctx->seed.used, ctx->seed.src, ctx->seed.mstate, ctx->seed.tile_tmp, ctx->seed.totals, ctx->seed.stacks,
@@ -170,6 +171,7 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	if (e == hipSuccess) e = hipMemset(ctx->d_tg, 0, na * 8);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_sumq, nr * 8);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_units, (na / 2 + 1) * sizeof(Unit));
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_unit_aux, (na / 2 + 1) * sizeof(chaindp::UnitAux));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 2 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left, (na / 2 + 1) * sizeof(Unit));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left_cnt, 3 * sizeof(unsigned long long));
@@ -241,7 +243,7 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		es.n = 3;
 	}
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[0], st));
-	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, d_f, d_p, d_v, ctx->cmp.flags));
+	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, d_f, d_p, d_v, ctx->cmp.flags, ctx->d_unit_aux));
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[1], st));
 	// per-read gap-cost table for the fast variant (skipped when the table would not apply)
 	uint16_t *lut = nullptr;
@@ -268,10 +270,10 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 	unsigned int *const deep_cnt = (unsigned int*)(ctx->d_left_cnt + 1);
 	if (ctx->variant == 0 && lut && d_n_segs == nullptr) {
 		// ordinary units two per wave; what that kernel hands over (and nothing else) goes through k_chain_units
-		if (total > 0) HIP_TRY(ctx, hipMemsetAsync(ctx->d_first_child, 0x7f, (size_t)total * 4, st));   // NO_CHILD everywhere (chaindp_wave.h)
+		// (first_child[] is initialised by the DP kernels themselves, per tile: no batch-wide memset)
 		HIP_TRY(ctx, chaindp::launch_chain_twin(st, q, total / 2, d_off, d_a, ctx->d_sumq, lut, lut_stride, ctx->d_units, ctx->d_counters,
 		                                        d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->d_left, (unsigned int*)ctx->d_left_cnt,
-		                                        ctx->twin_force_left ? 1 : 0, total));
+		                                        ctx->twin_force_left ? 1 : 0, total, ctx->d_unit_aux));
 		const int64_t left_grid = total / 2 < 32768 ? total / 2 : 32768;
 		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, left_grid, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_left,
 		                                   ctx->d_left_cnt, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,

@@ -6,6 +6,7 @@
 // between its host buffer and its CSR slot in HBM with 16-byte (anchors) / 8-byte (24-byte records) lanes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "chaindp_kernels.h"
 
 namespace chaindp {
@@ -59,6 +60,16 @@ __global__ __launch_bounds__(256) void k_copy_out(int64_t n16, const io_u32x4 *_
 		__builtin_nontemporal_store(src[k], &dst[k]);
 }
 
+// Workgroups of the per-read movers.  They are PCIe-bound: a workgroup per read (thousands) fills every wave slot of the chip with
+// waves that wait for the link, and the DP kernels of the other contexts of a pipeline cannot start beside them; 64 workgroups of
+// 256 threads keep ~260 KB in flight, which covers the link's bandwidth-delay product several times over.
+static int io_blocks(int64_t n_reads)
+{
+	static const int cap = getenv("CHAINDP_IO_BLOCKS") ? atoi(getenv("CHAINDP_IO_BLOCKS")) : 64;     // (read once; tuning only)
+	const int64_t c = cap > 0 ? cap : 64;
+	return (int)(n_reads < c ? n_reads : c);
+}
+
 hipError_t launch_copy_out(hipStream_t st, void *h_dst, const void *d_src, size_t bytes, int blocks)
 {
 	const int64_t n16 = (int64_t)((bytes + 15) / 16);
@@ -70,7 +81,7 @@ hipError_t launch_copy_out(hipStream_t st, void *h_dst, const void *d_src, size_
 hipError_t launch_scatter_words(hipStream_t st, int64_t n_reads, const int64_t *d_woff, void *const *d_dst, const void *d_words)
 {
 	if (n_reads <= 0) return hipSuccess;
-	const int64_t blocks = n_reads < 65535 ? n_reads : 65535;
+	const int64_t blocks = io_blocks(n_reads);
 	hipLaunchKernelGGL(k_scatter_words, dim3((unsigned)blocks), dim3(256), 0, st, n_reads, d_woff,
 	                   (unsigned long long *const *)d_dst, (const unsigned long long*)d_words);
 	return hipGetLastError();
@@ -79,7 +90,7 @@ hipError_t launch_scatter_words(hipStream_t st, int64_t n_reads, const int64_t *
 hipError_t launch_gather_reads(hipStream_t st, int64_t n_reads, const int64_t *d_off, const void *const *d_src, void *d_a)
 {
 	if (n_reads <= 0) return hipSuccess;
-	const int64_t blocks = n_reads < 65535 ? n_reads : 65535;
+	const int64_t blocks = io_blocks(n_reads);
 	hipLaunchKernelGGL(k_gather_reads, dim3((unsigned)blocks), dim3(256), 0, st, n_reads, d_off,
 	                   (const ulonglong2 *const *)d_src, (ulonglong2*)d_a);
 	return hipGetLastError();
@@ -88,7 +99,7 @@ hipError_t launch_gather_reads(hipStream_t st, int64_t n_reads, const int64_t *d
 hipError_t launch_scatter_seeds(hipStream_t st, int64_t n_reads, const int64_t *d_seeds_off, void *const *d_dst, const void *d_seeds)
 {
 	if (n_reads <= 0) return hipSuccess;
-	const int64_t blocks = n_reads < 65535 ? n_reads : 65535;
+	const int64_t blocks = io_blocks(n_reads);
 	hipLaunchKernelGGL(k_scatter_seeds, dim3((unsigned)blocks), dim3(256), 0, st, n_reads, d_seeds_off,
 	                   (unsigned long long *const *)d_dst, (const unsigned long long*)d_seeds);
 	return hipGetLastError();

@@ -19,6 +19,15 @@ struct Unit {
 	int32_t len;     // upper bound of its length (next unit's start or end of the read)
 };
 
+// What k_chain_twin needs of a unit besides its record, so that picking a unit up costs it no trips to sumq[] / off[] / the table:
+// written by the prepass next to the unit list (same order).
+struct UnitAux {
+	int32_t rel0;    // the unit's first anchor, relative to its read
+	uint32_t lutkey; // bits of the read's avg_qspan (chain.c:241): reads with equal keys have identical gap-cost tables
+	uint32_t flags;  // bit 0: not for k_chain_twin (segment ids, a table that does not fit int8, a zero q_span)
+	uint32_t pad;
+};
+
 // the anchor-parallel kernels of the prepass and of the compaction cut the batch into blocks of this many anchors
 #define CHAINDP_BLOCK_ANCHORS 1024
 
@@ -36,7 +45,7 @@ size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *bl
 // counters[0] = units emitted (low 32 bits) | singleton anchors resolved by the prepass (high 32 bits)
 hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off, const void *d_a,
                           unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
-                          int32_t *d_f, int32_t *d_p, int32_t *d_v, uint8_t *d_flags);
+                          int32_t *d_f, int32_t *d_p, int32_t *d_v, uint8_t *d_flags, UnitAux *d_unit_aux = nullptr);
 
 // Per-read gap-cost table (uint16), lut_stride entries per read (multiple of 8); usable while
 // bw <= CHAINDP_LUT_MAX_BW.  d_lut == nullptr makes every unit take the general (f64) variant.
@@ -80,7 +89,8 @@ hipError_t launch_chain_dense1(hipStream_t st, const Params &par, int64_t max_un
 hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
                              const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride, const Unit *d_units,
                              const unsigned long long *d_counters, int32_t *d_f, int32_t *d_p, int32_t *d_v,
-                             int32_t *d_first_child, uint8_t *d_flags, Unit *d_left, unsigned int *d_left_cnt, int force_left, int64_t total);
+                             int32_t *d_first_child, uint8_t *d_flags, Unit *d_left, unsigned int *d_left_cnt, int force_left, int64_t total,
+                             const UnitAux *d_unit_aux);
 size_t twin_lds_bytes();
 
 // exclusive scan of n uint64 items in place (d_tile_tmp: ceil(n/1024)+1 words), total to *d_total

@@ -204,7 +204,8 @@ __global__ void k_unit_bases(unsigned int *__restrict__ hist, unsigned int *__re
 #define SCAT_PER_THREAD 4
 __global__ __launch_bounds__(256) void k_unit_scatter(const unsigned long long *__restrict__ counters, const Unit *__restrict__ in,
                                                       const unsigned int *__restrict__ base, unsigned int *__restrict__ cursor,
-                                                      Unit *__restrict__ out)
+                                                      Unit *__restrict__ out, Params par, const int64_t *__restrict__ off,
+                                                      const unsigned long long *__restrict__ sumq, UnitAux *__restrict__ out_aux)
 {
 	__shared__ unsigned int s_cnt[UNIT_CLASSES], s_base[UNIT_CLASSES];
 	const int64_t n = (int64_t)(uint32_t)counters[0];
@@ -224,7 +225,23 @@ __global__ __launch_bounds__(256) void k_unit_scatter(const unsigned long long *
 		if (threadIdx.x < UNIT_CLASSES && s_cnt[threadIdx.x])
 			s_base[threadIdx.x] = base[threadIdx.x] + atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]);
 		__syncthreads();
-		for (int k = 0; k < SCAT_PER_THREAD; ++k) if (cls[k] >= 0) out[s_base[cls[k]] + rank[k]] = u[k];
+		for (int k = 0; k < SCAT_PER_THREAD; ++k) if (cls[k] >= 0) {
+			const unsigned int pos = s_base[cls[k]] + rank[k];
+			out[pos] = u[k];
+			if (out_aux) {
+				// what k_chain_twin would otherwise fetch per unit (sumq[], off[]): the unit's place in its read, the key of the read's
+				// cost table (same f32 divide as k_build_lut, chain.c:241) and whether the read is one for the general kernel
+				const int64_t rs = off[u[k].read], n = off[u[k].read + 1] - rs;
+				const unsigned long long sq = sumq[u[k].read];
+				const float avg = (float)(uint64_t)(sq & ~SUMQ_FLAGS) / (float)n;
+				const int lg = par.bw ? 31 - __builtin_clz((unsigned)par.bw) : 0;
+				const bool lut16 = 1 - ((int)((double)par.bw * .01 * (double)avg) + (lg >> 1)) < -128;   // the table's last entry (k_build_lut)
+				UnitAux ax;
+				ax.rel0 = (int32_t)(u[k].start - rs); ax.lutkey = __float_as_uint(avg);
+				ax.flags = ((sq & (SUMQ_SEG_FLAG | SUMQ_SPAN0_FLAG)) || lut16) ? 1u : 0u; ax.pad = 0;
+				out_aux[pos] = ax;
+			}
+		}
 		__syncthreads();
 	}
 }
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(256) void k_build_lut(Params par, int64_t n_reads, 
 
 hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off, const void *d_a,
                           unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
-                          int32_t *d_f, int32_t *d_p, int32_t *d_v, uint8_t *d_flags)
+                          int32_t *d_f, int32_t *d_p, int32_t *d_v, uint8_t *d_flags, UnitAux *d_unit_aux)
 {
 	hipError_t e = hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st);
 	if (e != hipSuccess || n_reads <= 0 || total <= 0) return e;
@@ -274,7 +291,7 @@ hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, in
 	                   sc.start_mask, sc.block_cnt, sc.units_tmp, sc.hist, sc.block_reads);
 	hipLaunchKernelGGL(k_unit_bases, dim3(1), dim3(64), 0, st, sc.hist, sc.hist + UNIT_CLASSES);
 	hipLaunchKernelGGL(k_unit_scatter, dim3((unsigned)(blocks < 1024 ? (blocks > 0 ? blocks : 1) : 1024)), dim3(256), 0, st, d_counters, sc.units_tmp,
-	                   sc.hist, sc.hist + UNIT_CLASSES, d_units);
+	                   sc.hist, sc.hist + UNIT_CLASSES, d_units, par, d_off, d_sumq, d_unit_aux);
 	return hipGetLastError();
 }
 

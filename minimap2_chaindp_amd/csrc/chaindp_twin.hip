@@ -30,7 +30,8 @@
 //   ST  [2 halves] 56 B             the half's cold state (TwinCold) and what a scan carries into its second chunk
 //   MK  [2 halves][65] 4 B          marks by distance: word d-1 holds the scan tag of the anchor d behind; word 64 = sink
 //   SP  [2 halves][64] 1 B          q_span - 1 of the current tile's anchors (entry n of XQ at byte a has its SP byte at a / 8 + const)
-// 6392 bytes.  LDS is handed out in pieces of 1280 bytes on this chip (tools/lds_occupancy_probe.hip measures how many workgroups
+//   KEY [2 halves] 4 B              which read's table the half's LUT holds (reads with the same avg_qspan share it)
+// 6400 bytes.  LDS is handed out in pieces of 1280 bytes on this chip (tools/lds_occupancy_probe.hip measures how many workgroups
 // a CU holds; the occupancy API does not know): 6400 bytes are the most that leave 24 waves per CU, i.e. six per SIMD.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -57,7 +58,8 @@ namespace chaindp {
 #define TW_SP 6264u
 #define TW_SP_HALF 64u
 #define TW_SP_OF_XQ (TW_SP - TW_XQ / 8u)  // SP address = (XQ address >> 3) + this
-#define TW_LDS_BYTES 6392u
+#define TW_KEY 6392u                    // [2 halves] 4 B: key of the cost table the half's LUT holds (UnitAux::lutkey)
+#define TW_LDS_BYTES 6400u
 #define TW_TILE 64                      // anchors a half takes in / flushes at a time
 #define TW_RING 64                      // predecessors a scan can reach in this kernel (two chunks of 32)
 #define TW_QCH 8                        // units a half takes from the queue at a time
@@ -66,6 +68,13 @@ namespace chaindp {
 #define TW_LDS(T, a) ((__attribute__((address_space(3))) T*)(a))
 #else
 #define TW_LDS(T, a) ((T*)(uintptr_t)(a))          /* host pass of the single-source compile; never executed */
+#endif
+// unit records and their UnitAux are read through the scalar cache: a load from the constant address space with a wave-uniform
+// address is an s_load (the arrays are written by the prepass, never by this kernel)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TW_CONST(T, p) ((const __attribute__((address_space(4))) T*)(uintptr_t)(p))
+#else
+#define TW_CONST(T, p) ((const T*)(p))
 #endif
 typedef uint32_t tw_u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t tw_u32x4 __attribute__((ext_vector_type(4)));
@@ -196,6 +205,7 @@ struct TwinArgs {
 	const uint16_t *lut;
 	int lut_stride;
 	const Unit *units;
+	const UnitAux *aux;               // beside units[]: rel0, table key, "general" flag
 	const unsigned long long *counters;
 	int32_t *f, *p, *v;
 	int32_t *first_child;
@@ -239,12 +249,19 @@ struct TwinHot {
 #if defined(CHAINDP_TWIN_STAMPS) && CHAINDP_TWIN_STAMPS == 2
 #define TW_STAMP_A(...)
 #define TW_STAMP_B(...) __VA_ARGS__
-#elif defined(CHAINDP_TWIN_STAMPS)
+#elif defined(CHAINDP_TWIN_STAMPS) && CHAINDP_TWIN_STAMPS == 1
 #define TW_STAMP_A(...) __VA_ARGS__
 #define TW_STAMP_B(...)
 #else
 #define TW_STAMP_A(...)
 #define TW_STAMP_B(...)
+#endif
+// build 3: inside the unit switch (head: until the unit's record is there; take: until its first tile is there; tail: table, ring
+// initialisation and the tile taken; n_unit counts the first tiles that were requested ahead)
+#if defined(CHAINDP_TWIN_STAMPS) && CHAINDP_TWIN_STAMPS == 3
+#define TW_STAMP_C(...) __VA_ARGS__
+#else
+#define TW_STAMP_C(...)
 #endif
 #define TW_NOW() __builtin_amdgcn_s_memtime()
 
@@ -304,11 +321,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 		tw_st64(st_addr + 16u, 0u, 0u); tw_st64(st_addr + 24u, 0u, 0u);                 // x_carry, rel0, room
 		tw_st64(st_addr + 32u, 0u, (uint32_t)-TW_TILE);                                 // read, tile0
 		tw_st64(st_addr + TW_CARRY, 0xfffffffcu, 0u); tw_st64(st_addr + TW_CARRY + 8u, 0u, 0u);   // carry, second chunks so far
+		tw_st32(TW_KEY + 4u * (uint32_t)h, -1);                                         // no table yet (an avg_qspan is never a NaN)
 	}
 	wave_mem_fence();
 
 	TW_STAMP(unsigned long long st_t0 = 0; unsigned int st_service = 0, st_n_service = 0, st_n_fast = 0, st_flush = 0, st_unit = 0, st_n_unit = 0, st_head = 0, st_take = 0, st_tail = 0;)   // (32-bit sums: a wave's ticks fit, and the build has no registers to spare)
 	uint64_t nx0_x = 0, nx0_y = 0, nx1_x = 0, nx1_y = 0;           // each half's NEXT tile, requested a tile ahead (one anchor per lane; zeros where the unit has none)
+	int32_t pfu0 = -1, pfu1 = -1;                                  // ... or, when the unit ends with the current tile, the first tile of the half's NEXT
+	                                                               // unit: its first anchor's global index (wave-uniform), -1 = the registers hold no such tile
 
 	// One service round for the halves in `svc`, whose tile is exhausted (or which have no unit yet).  One half at a time, by ALL 64
 	// lanes of the wave (a tile is 64 anchors, one per lane): everything that is per half (the cold state, the unit being picked,
@@ -318,6 +338,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 	// for those stores --, then the finished tile is flushed; a half whose unit is over picks its next unit and loads that one's
 	// first tile.  Once per 64 anchors and half.
 	auto service = [&](uint64_t svc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (whatever is outstanding was issued a tile of passes ago: no wait in practice)
+#endif
 		wave_mem_fence();
 		uint64_t retired = 0;
 		for (int hs = 0; hs < 2; ++hs) {
@@ -334,9 +357,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 			int c_rel0 = (int)TW_UNI(cw3.x), c_room = (int)TW_UNI(cw3.y), c_read = (int)TW_UNI(cw4.x), c_tile0 = (int)TW_UNI(cw4.y);
 			const int cnt_prev = (int)(((uint32_t)__builtin_amdgcn_readlane((int)u.pend, 32 * hs) - curb) >> 3);   // anchors of the tile that has just been scored
 			const int slow_h = (int)TW_UNI((uint32_t)tw_ld32(sa + TW_CARRY + 12u));
+			const uint32_t cur_key = TW_UNI((uint32_t)tw_ld32(TW_KEY + 4u * (uint32_t)hs));
 			const int tile_prev = c_tile0, rel0_prev = c_rel0;
 			const int64_t base_prev = c_base;
 			bool live = true;
+			// The half's next unit (and the one after it), when this call will need them -- the unit ends here, or with the tile taken
+			// now (its successor's first tile is then requested a tile ahead, like any other tile): records and UnitAux through the
+			// scalar cache, issued before the work below and read after it.
+			const uint32_t nx0 = (uint32_t)c_next, ne0 = (uint32_t)((uint64_t)c_next >> 32);
+			tw_u32x4 rec0 = {0u, 0u, 0u, 0u}, aux0 = {0u, 0u, 0u, 0u}, rec1 = {0u, 0u, 0u, 0u};
+			const bool rec0_ok = nx0 < ne0 && (int64_t)nx0 < n_units;       // (whenever they are known: a unit can end before its bound says so)
+			const bool rec1_ok = rec0_ok && nx0 + 1u < ne0 && (int64_t)nx0 + 1 < n_units;
+			if (rec0_ok) { rec0 = *TW_CONST(tw_u32x4, g.units + nx0); aux0 = *TW_CONST(tw_u32x4, g.aux + nx0); }
+			if (rec1_ok) rec1 = *TW_CONST(tw_u32x4, g.units + nx0 + 1u);
 
 			// takes a tile's anchors (one per lane, raw mm128_t) into the half's LDS: where the unit ends (first gap > max_dist_x,
 			// chain.c:252), XY ring (the anchors as predecessors), XQ / SP (as the current anchor).  Returns the anchors the tile holds
@@ -362,12 +395,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 					tw_st64((((uint32_t)i_lane & 127u) << 4 | (uint32_t)hs << 3) + TW_XY, (uint32_t)an_x + 1u, (uint32_t)an_y + 1u);
 					tw_st64(curb + ((uint32_t)lane << 3), (uint32_t)an_x, (uint32_t)an_y);
 					tw_st8(spb + (uint32_t)lane, sp - 1);
+					// first_child[] starts at "none" for every anchor the kernel takes in: stored here, a whole tile of passes before the
+					// tile's flush (or any later one) lowers it with atomics -- and service() waits for the wave's outstanding memory
+					// operations when it starts, so those atomics come after this store in memory as well.  No batch-wide memset.
+					g.first_child[c_base + i_lane] = NO_CHILD;
 				}
 				wave_mem_fence();
 				// the tile after this one: the load is issued now and read at the half's next service, 64 anchors of work later
-				uint64_t rx = 0, ry = 0;
-				if (cnt == TW_TILE && i_lane + TW_TILE < c_room) { const ulonglong2 t = g.a[c_base + i_lane + TW_TILE]; rx = t.x; ry = t.y; }
-				if (hs) { nx1_x = rx; nx1_y = ry; } else { nx0_x = rx; nx0_y = ry; }
+				if (cnt == TW_TILE && c_tile0 + TW_TILE < c_room) {            // (else: the unit ends with this tile; the registers are for its successor)
+					uint64_t rx = 0, ry = 0;
+					if (i_lane + TW_TILE < c_room) { const ulonglong2 t = g.a[c_base + i_lane + TW_TILE]; rx = t.x; ry = t.y; }
+					if (hs) { nx1_x = rx; nx1_y = ry; pfu1 = -1; } else { nx0_x = rx; nx0_y = ry; pfu0 = -1; }
+				}
 				return cnt;
 			};
 
@@ -420,8 +459,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				wave_mem_fence();
 				if (have) tw_st32((((uint32_t)i_lane & 63u) << 3 | (uint32_t)hs << 2) + TW_V, val | (self ? INT_MIN : 0));
 				wave_mem_fence();
-				// (first_child[] of the whole batch is NO_CHILD when this kernel starts -- one memset by the host -- so that no tile has
-				// to store it and wait for the store before its children's atomics)
+				// (first_child[] of the tile's anchors is NO_CHILD since the tile was taken in)
 				if (have) {
 					g.f[gi] = fi;
 					g.p[gi] = pi < 0 ? -1 : pi + rel0_prev;
@@ -435,36 +473,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 			TW_STAMP_A(const unsigned long long tu0 = g.stamp ? TW_NOW() : 0;)
 			TW_STAMP_A(if (g.stamp && !goes_on) ++st_n_unit;)
 			// ---- the unit is over: the half's next unit (units that are not for this kernel are handed over), its LDS, its first tile
+			bool have_rec = rec0_ok;                                       // rec0 / aux0 are the records of unit c_next
+			const bool rec0_used = !goes_on;                               // the loop below takes unit nx0 (or hands it over)
+			uint32_t cur_key_now = cur_key;
 			while (!goes_on && live) {
-				Unit un;
-				for (;;) {
-					uint32_t nx = (uint32_t)c_next, ne = (uint32_t)((uint64_t)c_next >> 32);
-					if (nx >= ne) {
-						// the chunk is used up: the next TW_QCH units nobody has taken (the list is longest first, so the two halves of a
-						// wave, and all waves, work on units of similar length at any time and run out of work together)
-						uint32_t q0 = 0;
-						if (lane == 0) q0 = atomicAdd(g.queue, (unsigned int)TW_QCH);
-						nx = TW_UNI(q0); ne = nx + TW_QCH;
-					}
-					if ((int64_t)nx >= n_units) { c_next = (int64_t)((uint64_t)ne << 32 | nx); live = false; break; }
-					un = g.units[nx];
-					c_next = (int64_t)((uint64_t)ne << 32 | (nx + 1u));
-					const unsigned long long sq = g.sumq[un.read];
-					const bool general = !params_ok || (sq & (SUMQ_SEG_FLAG | SUMQ_LUT16_FLAG | SUMQ_SPAN0_FLAG)) || g.par.n_segs > 1;
-					if (!general) break;
-					if (lane == 0) g.left[atomicAdd(g.left_cnt, 1u)] = un;     // not for this kernel: hand the unit over
+				uint32_t nx = (uint32_t)c_next, ne = (uint32_t)((uint64_t)c_next >> 32);
+				if (nx >= ne) {
+					// the chunk is used up: the next TW_QCH units nobody has taken (the list is longest first, so the two halves of a
+					// wave, and all waves, work on units of similar length at any time and run out of work together)
+					uint32_t q0 = 0;
+					if (lane == 0) q0 = atomicAdd(g.queue, (unsigned int)TW_QCH);
+					nx = TW_UNI(q0); ne = nx + TW_QCH;
+					have_rec = false;
 				}
-				if (!live) { u.pc = TW_SEL(hm, curb, u.pc); u.pend = TW_SEL(hm, curb, u.pend); break; }
-				c_base = un.start; c_rel0 = (int)(un.start - g.off[un.read]); c_room = un.len; c_read = un.read; c_tile0 = 0;
-				// LDS of the half for a new unit: marks never match, every XY slot fails the window test, the read's table (as bytes)
-				const uint2 *src = (const uint2*)(g.lut + (int64_t)c_read * g.lut_stride);
-				uint64_t tl_x = 0, tl_y = 0;
-				if (lane < c_room) { const ulonglong2 t = g.a[c_base + lane]; tl_x = t.x; tl_y = t.y; }   // the unit's first tile
+				if ((int64_t)nx >= n_units) {
+					c_next = (int64_t)((uint64_t)ne << 32 | nx); live = false;
+					u.pc = TW_SEL(hm, curb, u.pc); u.pend = TW_SEL(hm, curb, u.pend);
+					break;
+				}
+				TW_STAMP_C(const unsigned long long tc0 = g.stamp ? TW_NOW() : 0;)
+				if (!have_rec) { rec0 = *TW_CONST(tw_u32x4, g.units + nx); aux0 = *TW_CONST(tw_u32x4, g.aux + nx); }
+				have_rec = false;
+				TW_STAMP_C(if (g.stamp) { asm volatile("" :: "s"(rec0.x), "s"(aux0.x)); st_head += (unsigned int)(TW_NOW() - tc0); })
+				c_next = (int64_t)((uint64_t)ne << 32 | (nx + 1u));
+				Unit un;
+				un.start = (int64_t)((uint64_t)rec0.y << 32 | rec0.x); un.read = (int32_t)rec0.z; un.len = (int32_t)rec0.w;
+				if (!params_ok || (aux0.z & 1u) || g.par.n_segs > 1) {         // not for this kernel: hand the unit over
+					if (lane == 0) g.left[atomicAdd(g.left_cnt, 1u)] = un;
+					continue;
+				}
+				c_base = un.start; c_rel0 = (int)aux0.x; c_room = un.len; c_read = un.read; c_tile0 = 0;
+				// the unit's first tile: requested a tile ago if the unit before it ended as foreseen
+				uint64_t tl_x, tl_y;
+				TW_STAMP_C(const unsigned long long tc1 = g.stamp ? TW_NOW() : 0;)
+				TW_STAMP_C(if (g.stamp && (hs ? pfu1 : pfu0) == (int32_t)c_base) ++st_n_unit;)
+				if ((hs ? pfu1 : pfu0) == (int32_t)c_base) { tl_x = hs ? nx1_x : nx0_x; tl_y = hs ? nx1_y : nx0_y; }
+				else {
+					tl_x = 0; tl_y = 0;
+					if (lane < c_room) { const ulonglong2 t = g.a[c_base + lane]; tl_x = t.x; tl_y = t.y; }
+				}
+				if (hs) pfu1 = -1; else pfu0 = -1;
+				TW_STAMP_C(if (g.stamp) { asm volatile("" :: "v"(tl_x), "v"(tl_y)); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_take += (unsigned int)(TW_NOW() - tc1); })
+				TW_STAMP_C(const unsigned long long tc2 = g.stamp ? TW_NOW() : 0;)
+				// LDS of the half for a new unit: marks never match, every XY slot fails the window test, the read's table (as bytes) unless
+				// the table in place is that of a read with the same avg_qspan
 				wave_mem_fence();
-				for (int k = lane; k * 4 <= g.par.bw; k += 64) {               // lut_stride is a multiple of 8 entries: whole uint2 loads
-					const uint2 t = src[k];
-					const uint32_t w = (t.x & 0xffu) | (t.x >> 8 & 0xff00u) | (t.y << 16 & 0xff0000u) | (t.y << 8 & 0xff000000u);
-					tw_st32(lutb + ((uint32_t)k << 2), (int)w);
+				if (aux0.y != cur_key_now) {
+					const uint2 *src = (const uint2*)(g.lut + (int64_t)c_read * g.lut_stride);
+					for (int k = lane; k * 4 <= g.par.bw; k += 64) {           // lut_stride is a multiple of 8 entries: whole uint2 loads
+						const uint2 t = src[k];
+						const uint32_t w = (t.x & 0xffu) | (t.x >> 8 & 0xff00u) | (t.y << 16 & 0xff0000u) | (t.y << 8 & 0xff000000u);
+						tw_st32(lutb + ((uint32_t)k << 2), (int)w);
+					}
+					cur_key_now = aux0.y;
+					if (lane == 0) tw_st32(TW_KEY + 4u * (uint32_t)hs, (int)cur_key_now);
 				}
 				const uint32_t x_none = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tl_x, 0) - (uint32_t)maxx - 1u;   // "no anchor here" (x+1 encoding)
 				for (int k = lane; k < 128; k += 64) tw_st64(((uint32_t)k << 4 | (uint32_t)hs << 3) + TW_XY, x_none, 0u);
@@ -473,6 +535,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				c_xcarry = 0;
 				if (lane == 0) tw_st32(sa + TW_CARRY + 12u, 0);
 				if (take_tile(tl_x, tl_y) > 0) goes_on = true;                 // (a unit has at least two anchors: always)
+				TW_STAMP_C(if (g.stamp) { st_tail += (unsigned int)(TW_NOW() - tc2); ++st_unit; })
+			}
+			// ---- the unit ends with the tile just taken: request its successor's first tile now, if the successor is known
+			if (live) {
+				const uint32_t cnt_now = ((uint32_t)__builtin_amdgcn_readlane((int)u.pend, 32 * hs) - curb) >> 3;
+				const uint32_t nxn = (uint32_t)c_next, nen = (uint32_t)((uint64_t)c_next >> 32);
+				if (!(cnt_now == TW_TILE && c_tile0 + TW_TILE < c_room) && (hs ? pfu1 : pfu0) < 0 && nxn < nen && (int64_t)nxn < n_units &&
+				    ((nxn == nx0 && rec0_ok && !rec0_used) || (nxn == nx0 + 1u && rec1_ok))) {
+					const tw_u32x4 rn = nxn == nx0 ? rec0 : rec1;                // (nxn == nx0: the loop above did not run, rec0 is untouched)
+					const int32_t st = (int32_t)rn.x, ln = (int32_t)rn.w;
+					uint64_t rx = 0, ry = 0;
+					if (lane < ln) { const ulonglong2 t = g.a[(int64_t)st + lane]; rx = t.x; ry = t.y; }
+					if (hs) { nx1_x = rx; nx1_y = ry; pfu1 = st; } else { nx0_x = rx; nx0_y = ry; pfu0 = st; }
+				}
 			}
 			TW_STAMP_A(if (g.stamp) st_unit += (unsigned int)(TW_NOW() - tu0);)
 			// ---- the tile's first anchor becomes current
@@ -675,9 +751,11 @@ size_t twin_lds_bytes() { return TW_LDS_BYTES; }
 hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
                              const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride, const Unit *d_units,
                              const unsigned long long *d_counters, int32_t *d_f, int32_t *d_p, int32_t *d_v,
-                             int32_t *d_first_child, uint8_t *d_flags, Unit *d_left, unsigned int *d_left_cnt, int force_left, int64_t total)
+                             int32_t *d_first_child, uint8_t *d_flags, Unit *d_left, unsigned int *d_left_cnt, int force_left, int64_t total,
+                             const UnitAux *d_unit_aux)
 {
 	if (max_units <= 0) return hipSuccess;
+	if (!d_unit_aux) return hipErrorInvalidValue;
 	// persistent waves: as many as the chip holds at the kernel's occupancy (6 per SIMD), each half taking units from a queue
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -691,7 +769,7 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
 	}
 	TwinArgs g;
 	g.par = par; g.off = d_off; g.a = (const ulonglong2*)d_a; g.sumq = d_sumq; g.lut = d_lut; g.lut_stride = lut_stride;
-	g.units = d_units; g.counters = d_counters; g.f = d_f; g.p = d_p; g.v = d_v; g.first_child = d_first_child; g.flags = d_flags;
+	g.units = d_units; g.aux = d_unit_aux; g.counters = d_counters; g.f = d_f; g.p = d_p; g.v = d_v; g.first_child = d_first_child; g.flags = d_flags;
 	g.left = d_left; g.left_cnt = d_left_cnt; g.queue = d_left_cnt + 1; g.force_left = force_left; g.total = total;
 	// diagnostic: CHAINDP_TWIN_STAMP=1 makes the kernel stamp where its waves' time goes (s_memtime: shader-clock ticks) and this
 	// function print the averages -- it synchronises, so never set it in a timed run
@@ -717,6 +795,7 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
 				const unsigned long long *o = &hb[(size_t)b * 12];
 				tot += o[0]; svc += o[1]; flush += o[2]; unit += o[3]; nsvc += o[4]; nfast += o[5]; nunit += o[6]; head += o[8]; take += o[9]; tail += o[10]; ++nb;
 			}
+			fprintf(stderr, "[twin stamp raw] sums over waves: head %.0f take %.0f tail %.0f unit %.0f n_unit %.0f (build 3: ticks until the record / the first tile / the rest of a unit switch; switches; first tiles requested ahead)\n", head, take, tail, unit, nunit);
 			fprintf(stderr, "[twin stamp] %.0f waves, %.0f ticks each: service %.1f%% (%.0f calls, %.0f ticks each: cold state and decisions %.0f, next tile %.0f, flush %.0f, "
 			                "unit switch %.0f (%.0f switches, %.0f ticks each), first anchor and cold state back %.0f), passes %.0f (%.0f ticks each, everything else included)\n",
 			        nb, tot / nb, 100.0 * svc / tot, nsvc, svc / (nsvc > 0 ? nsvc : 1), head / (nsvc > 0 ? nsvc : 1), take / (nsvc > 0 ? nsvc : 1), flush / (nsvc > 0 ? nsvc : 1),

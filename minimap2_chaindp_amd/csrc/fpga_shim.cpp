@@ -476,6 +476,12 @@ extern "C" void chaindp_fpga_configure_groups(int n_groups)
 	g.n_groups_cfg = n_groups > 0 ? n_groups : 0;
 }
 
+extern "C" void chaindp_fpga_configure_services(int contexts_per_group)
+{
+	std::lock_guard<std::mutex> lk(g.mu);
+	if (contexts_per_group >= 1 && contexts_per_group <= 8) g.services_per_gpu = contexts_per_group;
+}
+
 extern "C" void chaindp_fpga_configure_capacity(int64_t max_anchors_per_batch, int64_t max_reads_per_batch)
 {
 	std::lock_guard<std::mutex> lk(g.mu);

@@ -15,7 +15,7 @@ from .chaindp import SEED_DTYPE
 PKT_MINIMIZERS = 3        # the reference's task packets (map.c:302)
 PKT_ANCHORS = 0x41        # this build's: payload = the read's sorted anchors
 
-SHIM_EXTRA_SYMBOLS = ("chaindp_fpga_configure", "chaindp_fpga_configure_capacity", "chaindp_fpga_configure_groups", "chaindp_fpga_stats",
+SHIM_EXTRA_SYMBOLS = ("chaindp_fpga_configure", "chaindp_fpga_configure_capacity", "chaindp_fpga_configure_groups", "chaindp_fpga_configure_services", "chaindp_fpga_stats",
                       "chaindp_fpga_stats_gpu")
 
 DRIVER_SYMBOLS = (
@@ -79,6 +79,8 @@ def lib():
         L.chaindp_fpga_stats.argtypes = [vp]
         L.chaindp_fpga_configure_capacity.restype = None
         L.chaindp_fpga_configure_capacity.argtypes = [C.c_int64, C.c_int64]
+        L.chaindp_fpga_configure_services.restype = None
+        L.chaindp_fpga_configure_services.argtypes = [C.c_int]
         L.chaindp_fpga_configure_groups.restype = None
         L.chaindp_fpga_configure_groups.argtypes = [C.c_int]
         L.chaindp_fpga_stats_gpu.restype = C.c_int

@@ -6,7 +6,7 @@
  * build's anchor packets (type 0x41).  Prints one JSON line per round (PCIe-inclusive seconds, payload elements in,
  * new_seed records out) and a last one with the shim's batch counts and per-GPU shares.
  *   make -C minimap2_chaindp_amd/csrc shim_replay          (bench.py's packet_abi entry runs it)
- *   shim_replay <file> [producers=8] [reps=4] [rounds=3] [max_packets_per_batch=256] [n_gpus=0 (all)]
+ *   shim_replay <file> [producers=8] [reps=4] [rounds=3] [max_packets_per_batch=256] [n_gpus=0 (all)] [service contexts per GPU=0 (default)]
  * File: "SHIMRPL1", int32 flag, mid_occ, bw, max_skip, min_sc, n_packets; 4 x (int64 bytes, blob); n_packets x (uint32 size, packet).
  */
 #include <pthread.h>
@@ -60,17 +60,18 @@ static void *receiver(void *arg)
 
 int main(int argc, char **argv)
 {
-	if (argc < 2) { fprintf(stderr, "usage: shim_replay <file> [producers=8] [reps=4] [rounds=3] [max_packets_per_batch=256] [n_gpus=0]\n"); return 2; }
+	if (argc < 2) { fprintf(stderr, "usage: shim_replay <file> [producers=8] [reps=4] [rounds=3] [max_packets_per_batch=256] [n_gpus=0] [services=0]\n"); return 2; }
 	n_prod = argc > 2 ? atoi(argv[2]) : 8;
 	reps = argc > 3 ? atoi(argv[3]) : 4;
 	int rounds = argc > 4 ? atoi(argv[4]) : 3, k, round;
-	const int max_pk = argc > 5 ? atoi(argv[5]) : 256, n_gpus = argc > 6 ? atoi(argv[6]) : 0;
+	const int max_pk = argc > 5 ? atoi(argv[5]) : 256, n_gpus = argc > 6 ? atoi(argv[6]) : 0, services = argc > 7 ? atoi(argv[7]) : 0;
 	FILE *fp = fopen(argv[1], "rb");
 	char magic[8];
 	int32_t hdr[6];
 	if (!fp || fread(magic, 1, 8, fp) != 8 || memcmp(magic, "SHIMRPL1", 8) || fread(hdr, 4, 6, fp) != 6) { fprintf(stderr, "bad replay file\n"); return 1; }
 	n_packets = hdr[5];
 	chaindp_fpga_configure(n_gpus, max_pk, 0);
+	if (services > 0) chaindp_fpga_configure_services(services);
 	if (fpga_init(0) != 0) return 1;                                                                 /* main.c:512 */
 	for (k = 0; k < 4; ++k) {
 		int64_t nb;

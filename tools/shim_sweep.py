@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Writes the two replay files bench.py's packet_abi entry uses (anchor packets of the bench job's first reads, the reference's
+minimizer packets with the index image) and runs tools/shim_replay.c over them for several shim configurations.
+  python tools/shim_sweep.py [--trace]    (GPU box; results to stdout)"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import bench  # noqa: E402
+from minimap2_chaindp_amd import anchorgen, fpga, params as P  # noqa: E402
+
+par = P.preset("ava-ont")
+off, a = anchorgen.generate("ava-ont", n_reads=3300, seed=bench.SEED, threads=16)
+n = len(off) - 1
+packets = [fpga.build_task_packet([(r, a[int(off[r]):int(off[r + 1])]) for r in range(k, min(k + 8, n))], par.max_dist_x, par.max_dist_y) for k in range(0, n, 8)]
+pa = "/tmp/anchors.rpl"
+bench._replay_file(pa, packets, [np.zeros(0, np.uint8)] * 4, 0, 0, par)
+g = np.load(os.path.join(ROOT, "tests", "golden", "_big", "big_avaont.npz"), allow_pickle=False)
+pv = [int(x) for x in g["params"]]
+mpar = P.ChainParams(max_dist_x=pv[0], max_dist_y=pv[1], bw=pv[2], max_skip=pv[3], min_sc=pv[4], is_cdna=pv[5], n_segs=1)
+nr = len(g["bid"])
+reads = [(r, g["mini"][g["mini_off"][r]:g["mini_off"][r + 1]], int(g["bid"][r]), int(g["qlen"][r])) for r in range(nr)]
+mp = [fpga.build_task_packet(reads[k:k + 8], mpar.max_dist_x, mpar.max_dist_y, pkt_type=fpga.PKT_MINIMIZERS) for k in range(0, nr, 8)]
+pm = "/tmp/minimizers.rpl"
+bench._replay_file(pm, mp, [g["img_B"], g["img_H"], g["img_V"], g["img_P"]], g["flag"], g["mid_occ"], mpar)
+exe = os.path.join(ROOT, "minimap2_chaindp_amd", "csrc", "shim_replay")
+tot_a, tot_m = int(off[-1]), int(g["a_off"][-1])
+env = dict(os.environ)
+if "--trace" in sys.argv:
+    env["CHAINDP_SHIM_TRACE"] = "1"
+for name, path, reps, tot, cfgs in (("anchors", pa, 6, tot_a, ((8, 2, 256), (16, 2, 256), (16, 3, 256), (12, 2, 256))),
+                                    ("minimizers", pm, 40, tot_m, ((8, 3, 256), (8, 2, 256), (16, 3, 256)))):
+    for producers, services, max_pk in cfgs:
+        r = subprocess.run([exe, path, str(producers), str(reps), "6", str(max_pk), "0", str(services)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        rounds = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{"round"')]
+        secs = [d["seconds"] for d in rounds]
+        shim = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{"shim"')]
+        best = min(secs[2:]) if len(secs) > 2 else None
+        print(name, "producers", producers, "services", services, "max_packets", max_pk, "rounds", [round(x, 4) for x in secs],
+              "best G anchors/s", round(tot * reps / best / 1e9, 3) if best else None, "batches", shim[0]["shim"]["device_batches"] if shim else None, flush=True)
+        if "--trace" in sys.argv and name == "minimizers" and producers == 8 and services == 3:
+            print("\n".join(r.stderr.splitlines()[-14:]), flush=True)
