@@ -144,7 +144,8 @@ int chaindp_download_seeds(chaindp_ctx_t *ctx, int64_t first_seed, int64_t n_see
  * chaindp_upload_gather_ex selects it (pinned = 0 behaves like chaindp_upload_gather).
  * chaindp_scatter_seeds writes read r's new_seed[] (after chaindp_compact_offsets) to dst[r] and zero-fills
  * up to the next 64-byte boundary, the padding of the reference's result packets (map.c:543-545); dst[r] ==
- * NULL skips the read.  Asynchronous: chaindp_sync() before reading dst. */
+ * NULL skips the read.  dst[r] must be 16-byte aligned (the slots of a result packet are 64-byte aligned: the
+ * device writes them in 16-byte stores over PCIe).  Asynchronous: chaindp_sync() before reading dst. */
 int chaindp_upload_gather_ex(chaindp_ctx_t *ctx, int64_t n_reads, const int64_t *off,
                              const chaindp_anchor_t *const *read_anchors, const int32_t *n_segs_per_read, int pinned);
 int chaindp_scatter_seeds(chaindp_ctx_t *ctx, int64_t n_reads, chaindp_seed_t *const *dst);
@@ -168,8 +169,8 @@ int chaindp_collect_seeds(chaindp_ctx_t *ctx, const chaindp_index_t *idx, int fl
 int chaindp_download_mini_pos(chaindp_ctx_t *ctx, uint64_t *mini_pos);      /* mini_pos_off[n_reads] entries */
 /* The same with per-read buffers in PINNED host memory, moved by one kernel per direction (no staging copies):
  * read_mini[r] = read r's minimizers (mini_off gives the counts); dst[r] receives read r's mini_pos[] zero-padded
- * to 64 bytes (the reference's result packet layout, map.c:547-552), NULL skips the read.  The scatter is
- * asynchronous: chaindp_sync() before reading dst. */
+ * to 64 bytes (the reference's result packet layout, map.c:547-552), NULL skips the read; dst[r] 16-byte aligned.  The
+ * scatter is asynchronous: chaindp_sync() before reading dst. */
 int chaindp_collect_seeds_gather(chaindp_ctx_t *ctx, const chaindp_index_t *idx, int flag, int max_occ, int64_t n_reads,
                                  const int64_t *mini_off, const chaindp_anchor_t *const *read_mini, const uint32_t *bid,
                                  const int32_t *qlen, const int32_t *n_segs_per_read, int64_t *off, int32_t *rep_len,

@@ -743,6 +743,7 @@ extern "C" int chaindp_scatter_seeds(chaindp_ctx_t *ctx, int64_t n_reads, chaind
 {
 	if (!ctx) return CHAINDP_ERR_ARG;
 	if (n_reads != ctx->n_reads || (n_reads > 0 && !dst) || !ctx->d_seeds) { ctx->err = "scatter does not match the last compaction"; return CHAINDP_ERR_ARG; }
+	for (int64_t r = 0; r < n_reads; ++r) if ((uintptr_t)dst[r] & 15u) { ctx->err = "scatter destinations must be 16-byte aligned"; return CHAINDP_ERR_ARG; }
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int rc = stage_pointers(ctx, (const void *const *)dst, n_reads);
 	if (rc) return rc;
@@ -1008,6 +1009,7 @@ extern "C" int chaindp_scatter_mini_pos(chaindp_ctx_t *ctx, int64_t n_reads, uin
 {
 	if (!ctx) return CHAINDP_ERR_ARG;
 	if (n_reads != ctx->n_reads || (n_reads > 0 && !dst) || !ctx->d_mp_off) { ctx->err = "scatter does not match the last seed collection"; return CHAINDP_ERR_ARG; }
+	for (int64_t r = 0; r < n_reads; ++r) if ((uintptr_t)dst[r] & 15u) { ctx->err = "scatter destinations must be 16-byte aligned"; return CHAINDP_ERR_ARG; }
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	int rc = stage_pointers(ctx, (const void *const *)dst, n_reads);
 	if (rc) return rc;

@@ -119,6 +119,12 @@ hipError_t launch_scan_u64(hipStream_t st, int64_t n, unsigned long long *d_data
 // 16-byte load in flight per lane; a 256-thread block per 1024 anchors was bound by its own start-up latency).
 __device__ __forceinline__ unsigned int flag_word(const uint4 &v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 
+#define CNT_BLOCKS_PER_WAVE 4          // 1024-anchor blocks a wave of k_count takes: their flag loads are all in flight before the first is used
+__device__ __forceinline__ void flag_or(uint4 &v, int e, unsigned int bits)
+{
+	const unsigned int m = bits << (8 * (e & 3));
+	if ((e >> 2) == 0) v.x |= m; else if ((e >> 2) == 1) v.y |= m; else if ((e >> 2) == 2) v.z |= m; else v.w |= m;
+}
 __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t total,
                                                      const int64_t *__restrict__ off, const int32_t *__restrict__ p,
                                                      const int32_t *__restrict__ first_child,
@@ -126,42 +132,76 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t to
                                                      const int2 *__restrict__ block_reads, uint16_t *__restrict__ sub)
 {
 	const int lane = threadIdx.x & 63;
-	const int64_t blk = (int64_t)blockIdx.x * (CMP_BLOCK / 64) + (threadIdx.x >> 6);
-	const int64_t g0 = blk * CMP_PER_BLOCK;
-	if (g0 >= total) return;
-	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
-	const int64_t g = g0 + 16 * lane;
-	unsigned int mine = 0;
-	if (g < g1) {
-		uint4 v = *(const uint4*)(flags + g);                      // 16 flag bytes (the array is padded to 16 B)
-		const int n = g1 - g < 16 ? (int)(g1 - g) : 16;
-		if ((v.x | v.y | v.z | v.w) & 0x04040404u) {               // rare: someone here may be a first child
-			const int2 rr = block_reads[blk];
-			for (int e = 0; e < n; ++e) {
-				const unsigned int fl = (flag_word(v, e >> 2) >> (8 * (e & 3))) & 0xffu;
-				if (!(fl & 4u)) continue;
-				const int64_t ge = g + e;
-				const int64_t rs = off[rr.x == rr.y ? rr.x : read_of_c(off, rr.x, rr.y, ge)];
-				if (first_child[rs + p[ge]] == (int32_t)(ge - rs)) {
-					flags[ge] = (uint8_t)(fl | 1u);
-					const unsigned int bit = 1u << (8 * (e & 3));
-					if ((e >> 2) == 0) v.x |= bit; else if ((e >> 2) == 1) v.y |= bit; else if ((e >> 2) == 2) v.z |= bit; else v.w |= bit;
-				}
+	const int64_t blk0 = ((int64_t)blockIdx.x * (CMP_BLOCK / 64) + (threadIdx.x >> 6)) * CNT_BLOCKS_PER_WAVE;
+	if (blk0 * CMP_PER_BLOCK >= total) return;
+	// A wave per 1024-anchor block spent its life waiting: for one 16-byte load per lane, then -- walking its 16 anchors in step
+	// with the other lanes -- for two dependent loads (p, first_child) at every position where ANY lane had a candidate (110 us for
+	// 76 M anchors: 0.7 TB/s of a byte per anchor).  Now: four blocks per wave, their flag loads in flight together, and every
+	// lane takes its own candidates one after the other whatever their positions, so a wave waits as often as its busiest lane
+	// has candidates (two or three times), not sixteen times.
+	uint4 vv[CNT_BLOCKS_PER_WAVE];
+	int2 rr[CNT_BLOCKS_PER_WAVE];
+	unsigned long long cand = 0;                                    // bit 16 b + e: anchor e of this lane's 16 in block b may be a first child
+#pragma unroll
+	for (int b = 0; b < CNT_BLOCKS_PER_WAVE; ++b) {
+		const int64_t g = (blk0 + b) * CMP_PER_BLOCK + 16 * lane;
+		const int64_t g1 = (blk0 + b + 1) * CMP_PER_BLOCK < total ? (blk0 + b + 1) * CMP_PER_BLOCK : total;
+		vv[b] = make_uint4(0u, 0u, 0u, 0u);
+		rr[b] = make_int2(0, 0);
+		if (g < g1) { vv[b] = *(const uint4*)(flags + g); rr[b] = block_reads[blk0 + b]; }      // 16 flag bytes (the array is padded to 16 B)
+	}
+#pragma unroll
+	for (int b = 0; b < CNT_BLOCKS_PER_WAVE; ++b) {
+		const int64_t g = (blk0 + b) * CMP_PER_BLOCK + 16 * lane;
+		const int64_t g1 = (blk0 + b + 1) * CMP_PER_BLOCK < total ? (blk0 + b + 1) * CMP_PER_BLOCK : total;
+		const int n = g >= g1 ? 0 : g1 - g < 16 ? (int)(g1 - g) : 16;
+		for (int k = 0; k < 4; ++k) {
+			const unsigned int w = flag_word(vv[b], k) & 0x04040404u;
+			// bit 2 of byte j of word k -> bit 4 k + j
+			const unsigned int c4 = ((w >> 2) & 1u) | ((w >> 9) & 2u) | ((w >> 16) & 4u) | ((w >> 23) & 8u);
+			cand |= (unsigned long long)c4 << (16 * b + 4 * k);
+		}
+		if (n < 16) cand &= ~(((1ull << (16 - n)) - 1ull) << (16 * b + n));
+	}
+	while (__builtin_amdgcn_ballot_w64(cand != 0)) {
+		if (cand) {
+			const int bit = __builtin_ctzll(cand);
+			cand &= cand - 1;
+			const int b = bit >> 4, e = bit & 15;
+			const int64_t ge = (blk0 + b) * CMP_PER_BLOCK + 16 * lane + e;
+			const int2 r2 = b == 0 ? rr[0] : b == 1 ? rr[1] : b == 2 ? rr[2] : rr[3];
+			const int64_t rs = off[r2.x == r2.y ? r2.x : read_of_c(off, r2.x, r2.y, ge)];
+			if (first_child[rs + p[ge]] == (int32_t)(ge - rs)) {
+				const unsigned int fl = (flag_word(b == 0 ? vv[0] : b == 1 ? vv[1] : b == 2 ? vv[2] : vv[3], e >> 2) >> (8 * (e & 3))) & 0xffu;
+				flags[ge] = (uint8_t)(fl | 1u);
+				if (b == 0) flag_or(vv[0], e, 1u); else if (b == 1) flag_or(vv[1], e, 1u); else if (b == 2) flag_or(vv[2], e, 1u); else flag_or(vv[3], e, 1u);
 			}
 		}
-		for (int k = 0; k < 4; ++k) {
-			unsigned int w = flag_word(v, k);
-			const int left = n - 4 * k;
-			if (left <= 0) w = 0; else if (left < 4) w &= (1u << (8 * left)) - 1u;
-			mine += (unsigned int)__builtin_popcount(w & 0x03030303u);    // late + self per anchor
-		}
 	}
-	// records in front of each lane's 16 anchors inside the block: lets k_emit_seeds find the position of any anchor of an earlier
-	// block from block_base[] + this + at most 15 flag bytes
-	unsigned int incl = mine;
-	for (int d = 1; d < 64; d <<= 1) { const unsigned int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-	sub[blk * 64 + lane] = (uint16_t)(incl - mine);
-	if (lane == 63) block_cnt[blk] = incl;
+#pragma unroll
+	for (int b = 0; b < CNT_BLOCKS_PER_WAVE; ++b) {
+		const int64_t blk = blk0 + b;
+		const int64_t g0 = blk * CMP_PER_BLOCK;
+		if (g0 >= total) break;
+		const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
+		const int64_t g = g0 + 16 * lane;
+		unsigned int mine = 0;
+		if (g < g1) {
+			const int n = g1 - g < 16 ? (int)(g1 - g) : 16;
+			for (int k = 0; k < 4; ++k) {
+				unsigned int w = flag_word(vv[b], k);
+				const int left = n - 4 * k;
+				if (left <= 0) w = 0; else if (left < 4) w &= (1u << (8 * left)) - 1u;
+				mine += (unsigned int)__builtin_popcount(w & 0x03030303u);    // late + self per anchor
+			}
+		}
+		// records in front of each lane's 16 anchors inside the block: lets k_emit_seeds find the position of any anchor of an
+		// earlier block from block_base[] + this + at most 15 flag bytes
+		unsigned int incl = mine;
+		for (int d = 1; d < 64; d <<= 1) { const unsigned int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+		sub[blk * 64 + lane] = (uint16_t)(incl - mine);
+		if (lane == 63) block_cnt[blk] = incl;
+	}
 }
 
 // C3: positions.  block_base = exclusive scan of block_cnt.  Writes batch-global ids and seeds_off[r] at every
@@ -387,8 +427,10 @@ hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, in
 	if (total <= 0) return hipMemsetAsync(d_seeds_off, 0, (size_t)(n_reads + 1) * sizeof(int64_t), st);
 	const int64_t blocks = (total + CMP_PER_BLOCK - 1) / CMP_PER_BLOCK;
 	const dim3 g((unsigned)blocks), b(CMP_BLOCK);
-	const dim3 gw((unsigned)((blocks + CMP_BLOCK / 64 - 1) / (CMP_BLOCK / 64)));    // one wave per 1024-anchor block
-	hipLaunchKernelGGL(k_count, gw, b, 0, st, n_reads, total, d_off, d_p, d_first_child, sc.flags, sc.block_cnt, sc.block_reads, sc.sub);
+	const dim3 gw((unsigned)((blocks + CMP_BLOCK / 64 - 1) / (CMP_BLOCK / 64)));    // one wave per 1024-anchor block (k_positions)
+	const int64_t cw = (blocks + CNT_BLOCKS_PER_WAVE - 1) / CNT_BLOCKS_PER_WAVE;    // waves of k_count
+	const dim3 gc((unsigned)((cw + CMP_BLOCK / 64 - 1) / (CMP_BLOCK / 64)));
+	hipLaunchKernelGGL(k_count, gc, b, 0, st, n_reads, total, d_off, d_p, d_first_child, sc.flags, sc.block_cnt, sc.block_reads, sc.sub);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, sc.n_seeds)) != hipSuccess) return e;
 	static const bool two_pass = getenv("CHAINDP_COMPACT_TWO_PASS") != nullptr;   // (read once: not on the launch path)
 	if (two_pass) {                          // the earlier form (positions to id[], then records), kept for A/B runs

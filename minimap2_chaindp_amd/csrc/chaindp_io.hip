@@ -22,7 +22,22 @@ __global__ __launch_bounds__(256) void k_gather_reads(int64_t n_reads, const int
 	}
 }
 
-// dst[r][0 .. n_r*3) (8-byte words) <- seeds[seeds_off[r] .. seeds_off[r+1]); then zero up to the next 64-byte boundary
+// dst[r][0 .. n_r*3) (8-byte words) <- seeds[seeds_off[r] .. seeds_off[r+1]); then zero up to the next 64-byte boundary.
+// The destination (a slot of a pinned result packet, 64-byte aligned) is written in 16-byte stores: the link takes them better than
+// 8-byte ones (the kernel trace of a packet replay showed this mover alone on 83 % of the wall clock at 46 GB/s).  The source is
+// 8-byte aligned only (24-byte records), so a 16-byte store is fed by two 8-byte loads.
+typedef unsigned long long io_u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void scatter_words16(unsigned long long *__restrict__ d, const unsigned long long *__restrict__ s, int64_t nw)
+{
+	const int64_t n16 = (((nw * 8 + 63) & ~(int64_t)63) >> 4);                                // 16-byte words incl. the zero padding
+	for (int64_t k = threadIdx.x; k < n16; k += blockDim.x) {
+		io_u64x2 t;
+		t.x = 2 * k < nw ? s[2 * k] : 0ull;
+		t.y = 2 * k + 1 < nw ? s[2 * k + 1] : 0ull;
+		__builtin_nontemporal_store(t, (io_u64x2*)d + k);
+	}
+}
+
 __global__ __launch_bounds__(256) void k_scatter_seeds(int64_t n_reads, const int64_t *__restrict__ seeds_off,
                                                        unsigned long long *const *__restrict__ dst,
                                                        const unsigned long long *__restrict__ seeds)
@@ -30,9 +45,7 @@ __global__ __launch_bounds__(256) void k_scatter_seeds(int64_t n_reads, const in
 	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
 		unsigned long long *d = dst[r];
 		if (!d) continue;
-		const int64_t w0 = seeds_off[r] * 3, nw = (seeds_off[r + 1] - seeds_off[r]) * 3;      // 24 B = 3 words
-		const int64_t nw_pad = ((nw * 8 + 63) & ~(int64_t)63) >> 3;
-		for (int64_t k = threadIdx.x; k < nw_pad; k += blockDim.x) d[k] = k < nw ? seeds[w0 + k] : 0ull;
+		scatter_words16(d, seeds + seeds_off[r] * 3, (seeds_off[r + 1] - seeds_off[r]) * 3);   // 24 B = 3 words
 	}
 }
 
@@ -44,9 +57,7 @@ __global__ __launch_bounds__(256) void k_scatter_words(int64_t n_reads, const in
 	for (int64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
 		unsigned long long *d = dst[r];
 		if (!d) continue;
-		const int64_t w0 = woff[r], nw = woff[r + 1] - w0;
-		const int64_t nw_pad = ((nw * 8 + 63) & ~(int64_t)63) >> 3;
-		for (int64_t k = threadIdx.x; k < nw_pad; k += blockDim.x) d[k] = k < nw ? words[w0 + k] : 0ull;
+		scatter_words16(d, words + woff[r], woff[r + 1] - woff[r]);
 	}
 }
 

@@ -760,7 +760,8 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 	int64_t blocks = (max_units + 2 * TW_QCH - 1) / (2 * TW_QCH);
-	const int64_t cap = (int64_t)cus * 24;
+	static const int wg_per_cu = getenv("CHAINDP_TWIN_WG_PER_CU") ? atoi(getenv("CHAINDP_TWIN_WG_PER_CU")) : 24;   // (tuning: read once)
+	const int64_t cap = (int64_t)cus * (wg_per_cu >= 1 && wg_per_cu <= 24 ? wg_per_cu : 24);
 	if (blocks > cap) blocks = cap;
 	if (blocks < 1) blocks = 1;
 	{

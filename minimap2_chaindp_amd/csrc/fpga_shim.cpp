@@ -34,7 +34,9 @@ static_assert(sizeof(chaindp_seed_t) == 24, "struct new_seed must be 24 bytes");
 namespace {
 
 // Pinned buffers in power-of-two size classes, recycled.  Every buffer is either handed out (in_use_) or in a free list,
-// never both: a second release of the same pointer is refused instead of putting it into the free list twice.
+// never both: a second release of the same pointer is refused instead of putting it into the free list twice.  Buffers are
+// carved out of 64 MiB slabs: one hipHostMalloc per packet buffer (a millisecond each, thousands until enough of them
+// circulate) made the first seconds of a run several times slower than its steady state.
 class PinnedPool {
 public:
 	void *get(size_t bytes)
@@ -45,7 +47,16 @@ public:
 		auto &fl = free_[cap];
 		void *p = nullptr;
 		if (!fl.empty()) { p = fl.back(); fl.pop_back(); }
-		else if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+		else {
+			if (slab_left_ < cap) {
+				const size_t sz = cap > kSlab ? cap : kSlab;
+				void *sl = nullptr;
+				if (hipHostMalloc(&sl, sz, hipHostMallocDefault) != hipSuccess) return nullptr;
+				slabs_.push_back(sl);
+				slab_cur_ = (char*)sl; slab_left_ = sz;              // (what was left of the previous slab is given up: less than one buffer)
+			}
+			p = slab_cur_; slab_cur_ += cap; slab_left_ -= cap;
+		}
 		cap_of_[p] = cap;
 		in_use_[p] = bytes;
 		return p;
@@ -72,13 +83,18 @@ public:
 	void destroy()
 	{
 		std::lock_guard<std::mutex> g(mu_);
-		for (auto &kv : cap_of_) (void)hipHostFree(kv.first);
+		for (void *sl : slabs_) (void)hipHostFree(sl);
+		slabs_.clear(); slab_cur_ = nullptr; slab_left_ = 0;
 		cap_of_.clear(); free_.clear(); in_use_.clear();
 	}
 private:
+	static constexpr size_t kSlab = 64u << 20;
 	std::mutex mu_;
 	std::map<size_t, std::vector<void*>> free_;
 	std::unordered_map<void*, size_t> cap_of_, in_use_;
+	std::vector<void*> slabs_;
+	char *slab_cur_ = nullptr;
+	size_t slab_left_ = 0;
 };
 
 struct Submitted { void *buf; uint32_t size; size_t granted; };

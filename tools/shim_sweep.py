@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Writes the two replay files bench.py's packet_abi entry uses (anchor packets of the bench job's first reads, the reference's
 minimizer packets with the index image) and runs tools/shim_replay.c over them for several shim configurations.
-  python tools/shim_sweep.py [--trace]    (GPU box; results to stdout)"""
+  python tools/shim_sweep.py [--trace | --write-only]    (GPU box; results to stdout; --write-only: just /tmp/anchors.rpl and /tmp/minimizers.rpl)"""
 import json
 import os
 import subprocess
@@ -28,12 +28,15 @@ mp = [fpga.build_task_packet(reads[k:k + 8], mpar.max_dist_x, mpar.max_dist_y, p
 pm = "/tmp/minimizers.rpl"
 bench._replay_file(pm, mp, [g["img_B"], g["img_H"], g["img_V"], g["img_P"]], g["flag"], g["mid_occ"], mpar)
 exe = os.path.join(ROOT, "minimap2_chaindp_amd", "csrc", "shim_replay")
+if "--write-only" in sys.argv:
+    print("wrote", pa, pm)
+    sys.exit(0)
 tot_a, tot_m = int(off[-1]), int(g["a_off"][-1])
 env = dict(os.environ)
 if "--trace" in sys.argv:
     env["CHAINDP_SHIM_TRACE"] = "1"
-for name, path, reps, tot, cfgs in (("anchors", pa, 6, tot_a, ((8, 2, 256), (16, 2, 256), (16, 3, 256), (12, 2, 256))),
-                                    ("minimizers", pm, 40, tot_m, ((8, 3, 256), (8, 2, 256), (16, 3, 256)))):
+for name, path, reps, tot, cfgs in (("anchors", pa, 6, tot_a, ((8, 2, 256), (8, 3, 256))),
+                                    ("minimizers", pm, 40, tot_m, ((8, 3, 256), (8, 2, 256), (8, 4, 256)))):
     for producers, services, max_pk in cfgs:
         r = subprocess.run([exe, path, str(producers), str(reps), "6", str(max_pk), "0", str(services)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
         rounds = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{"round"')]
