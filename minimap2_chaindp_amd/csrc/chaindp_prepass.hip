@@ -81,6 +81,49 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_rea
 		if (g < g1 && lane == 0 && g > 0) xb_[k] = a[g - 1].x;
 		if (g < g1 && (lane == 63 || g + 1 == g1) && g + 1 < total) xe_[k] = a[g + 1].x;
 	}
+	if (one_read) {
+		// ---- the usual block: inside one read.  Same arithmetic as the general loop below with what is block-uniform hoisted (the
+		// read's bounds), neighbours by DPP shifts instead of LDS permutes, the rare per-anchor events (a segment id, a zero q_span)
+		// found by ballots, and the singleton stores through block-relative pointers: about half the instructions per anchor --
+		// the kernel was issue-bound, not bandwidth-bound (80 vector + 60 scalar instructions per 64 anchors at 3 TB/s).
+		const int64_t rs = off[rlo], re = off[rlo + 1];
+		int32_t *const fb = f + g0, *const pb = p + g0, *const vb = v + g0;
+		uint8_t *const flb = flags + g0;
+		unsigned int any_seg = 0, any_span0 = 0;
+#pragma unroll
+		for (int k = 0; k < PASSES; ++k) {
+			const int64_t gb = g0 + (int64_t)k * PRE_BLOCK;
+			if (gb >= g1) break;
+			const int t = k * PRE_BLOCK + (int)threadIdx.x;              // the anchor's place in the block
+			const int64_t g = g0 + t;
+			const bool have = g < g1;
+			const ulonglong2 an = an_[k];
+			const uint32_t xlo = (uint32_t)an.x, xhi = (uint32_t)(an.x >> 32);
+			uint32_t plo = (uint32_t)wave_shift_up1((int)xlo, 0), phi = (uint32_t)wave_shift_up1((int)xhi, 0);
+			uint32_t nlo = (uint32_t)dpp_or_old<DPP_WAVE_SHL1, 0xf>(0, (int)xlo), nhi = (uint32_t)dpp_or_old<DPP_WAVE_SHL1, 0xf>(0, (int)xhi);
+			if (lane == 0) { plo = (uint32_t)xb_[k]; phi = (uint32_t)(xb_[k] >> 32); }
+			if (lane == 63 || g + 1 == g1) { nlo = (uint32_t)xe_[k]; nhi = (uint32_t)(xe_[k] >> 32); }
+			const uint64_t xprev = (uint64_t)phi << 32 | plo, xnext = (uint64_t)nhi << 32 | nlo;
+			const uint32_t yhi = (uint32_t)(an.y >> 32);
+			const int span = have ? (int)(yhi & 0xffu) : 0;
+			const bool start = have && (g == rs || an.x - xprev > maxx);
+			const bool single = start && (g + 1 >= re || xnext - an.x > maxx);
+			any_seg |= have ? (yhi & 0x00ff0000u) : 0u;
+			any_span0 |= (have && span == 0) ? 1u : 0u;
+			if (single) {                                              // chain.c:251,283-284 with an empty window
+				fb[t] = span; pb[t] = -1; vb[t] = span;
+				flb[t] = (uint8_t)(span >= par.min_sc ? 2 | 8 : 0);       // emitted at its own step iff v >= min_sc (chain.c:304); bit3 = v >= min_sc
+			}
+			w_sum += (unsigned int)span;
+			const uint64_t em = __builtin_amdgcn_ballot_w64(start && !single);
+			const uint64_t sm = __builtin_amdgcn_ballot_w64(single);
+			if (lane == 0 && gb + (threadIdx.x & ~63) < g1) start_mask[(gb + (threadIdx.x & ~63)) >> 6] = em;
+			w_units += (unsigned int)__builtin_popcountll(em);
+			w_singles += (unsigned int)__builtin_popcountll(sm);
+		}
+		if (__builtin_amdgcn_ballot_w64(any_seg != 0) && lane == 0) atomicOr(&sumq[rlo], SUMQ_SEG_FLAG);      // rare: multi-segment reads only
+		if (__builtin_amdgcn_ballot_w64(any_span0 != 0) && lane == 0) atomicOr(&sumq[rlo], SUMQ_SPAN0_FLAG);  // (never, in minimap2's own anchors)
+	} else
 #pragma unroll
 	for (int k = 0; k < PASSES; ++k) {
 		const int64_t gb = g0 + (int64_t)k * PRE_BLOCK;

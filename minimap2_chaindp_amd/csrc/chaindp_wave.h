@@ -13,9 +13,10 @@ namespace chaindp {
 
 // ---------------------------------------------------------------- wave primitives (wave64, DPP)
 
-// dpp_ctrl encodings (gfx9 family): row_shr:n = 0x110+n, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+// dpp_ctrl encodings (gfx9 family): row_shr:n = 0x110+n, wave_shl:1 = 0x130, wave_shr:1 = 0x138, row_bcast:15 = 0x142, row_bcast:31 = 0x143
 #define DPP_ROW_SHR(n) (0x110 + (n))
 #define DPP_WAVE_SHR1 0x138
+#define DPP_WAVE_SHL1 0x130
 #define DPP_ROW_BCAST15 0x142
 #define DPP_ROW_BCAST31 0x143
 

@@ -81,6 +81,38 @@ def test_seeded_batches_match_oracle(dev, gen, gen_over, preset, par_over, n_rea
         assert seeds[int(soff[r]):int(soff[r + 1])].tobytes() == exp.tobytes(), (gen, preset, r)
 
 
+@pytest.mark.parametrize("variant", [0, 2], ids=["two_per_wave", "one_per_wave"])
+def test_zero_and_mixed_q_spans(dev, variant):
+    """k_chain_twin keeps scores minus one with a floor of zero, which is only right while q_span >= 1: a read with a zero q_span
+    must leave it for k_chain_units (SUMQ_SPAN0_FLAG, set by the prepass), the other reads of the same batch must not, and reads
+    whose spans differ (another avg_qspan: another cost table) must reload the table when a half moves from one to the next."""
+    dev.set_ring(128)
+    dev.set_variant(variant)
+    par = P.preset("ava-ont")
+    off, a = ag.generate("ava-ont", n_reads=60, seed=77)
+    a = a.copy()
+    rng = np.random.default_rng(5)
+    for r in range(60):
+        lo, hi = int(off[r]), int(off[r + 1])
+        if r % 3 == 0:                                     # every third read: a few anchors with q_span 0
+            idx = lo + rng.choice(hi - lo, size=max(1, (hi - lo) // 50), replace=False)
+            a[idx, 1] &= ~np.uint64(0xff << 32)
+        elif r % 3 == 1:                                   # every third read: its own span (1..40), so its own avg_qspan and table
+            a[lo:hi, 1] = (a[lo:hi, 1] & ~np.uint64(0xff << 32)) | np.uint64((1 + r % 40) << 32)
+    f, p, v = dev.chain_batch(par, off, a)
+    of, op, ov, _ = ol.oracle_batch(par, off, a, threads=8)
+    for name, x, y in (("f", f, of), ("p", p, op), ("v", v, ov)):
+        bad = np.flatnonzero(x != y)
+        assert bad.size == 0, (name, "first mismatch at anchor", int(bad[0]), int(x[bad[0]]), int(y[bad[0]]), "read", int(np.searchsorted(off, bad[0], side="right") - 1))
+    soff, seeds = dev.compact(par)
+    for r in range(0, 60, 5):
+        lo, hi = int(off[r]), int(off[r + 1])
+        exp = ol.oracle_compact(par, np.ascontiguousarray(a[lo:hi]), of[lo:hi].copy(), op[lo:hi].copy(), ov[lo:hi].copy())
+        assert seeds[int(soff[r]):int(soff[r + 1])].tobytes() == exp.tobytes(), r
+    if variant == 0:
+        assert dev.leftover_units() > 0                    # the reads with a zero span went to k_chain_units
+
+
 def test_general_variant_on_seeded_batches(dev):
     dev.set_ring(256)
     dev.set_variant(True)
