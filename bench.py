@@ -412,7 +412,7 @@ def measure_packet_abi(par, off, anchors, target_anchors=20_000_000, producers=8
             path = os.path.join(tmpdir, "anchors.rpl")
             _replay_file(path, packets, [np.zeros(0, np.uint8)] * 4, 0, 0, par)
             del packets
-            out["anchor_packets"] = _run_replay(path, producers, 15, 6, int(off[n]), services=2)
+            out["anchor_packets"] = _run_replay(path, producers, 25, 5, int(off[n]), services=2)
             out["anchor_packets"]["bytes_in_per_anchor"], out["anchor_packets"]["input"] = 16, f"first {n} reads of the bench job"
             os.unlink(path)
         except Exception as e:  # noqa: BLE001
@@ -429,11 +429,11 @@ def measure_packet_abi(par, off, anchors, target_anchors=20_000_000, producers=8
             reads = [(r, g["mini"][g["mini_off"][r]:g["mini_off"][r + 1]], int(g["bid"][r]), int(g["qlen"][r])) for r in range(nr)]
             packets = [fpga.build_task_packet(reads[k:k + 8], mpar.max_dist_x, mpar.max_dist_y, pkt_type=fpga.PKT_MINIMIZERS) for k in range(0, nr, 8)]
             tot_a = int(g["a_off"][-1]) if "a_off" in g.files else len(g["anchors"])
-            reps = max(1, int(round(15 * target_anchors / max(tot_a, 1))))       # ~300 M anchors a round: filling and draining the contexts' pipeline
+            reps = max(1, int(round(25 * target_anchors / max(tot_a, 1))))       # ~500 M anchors a round: filling and draining the contexts' pipeline
                                                                                  # (a device batch is ~10 M anchors, three in flight) must not weigh
             path = os.path.join(tmpdir, "minimizers.rpl")
             _replay_file(path, packets, [g["img_B"], g["img_H"], g["img_V"], g["img_P"]], g["flag"], g["mid_occ"], mpar)
-            out["minimizer_packets"] = _run_replay(path, producers, reps, 6, tot_a, services=3)
+            out["minimizer_packets"] = _run_replay(path, producers, reps, 5, tot_a, services=3)
             out["minimizer_packets"]["minimizers_per_s"] = out["minimizer_packets"].get("elements_in_per_s")
             out["minimizer_packets"]["input"] = f"{os.path.relpath(src, ROOT)} ({nr} reads, {int(g['mini_off'][-1])} minimizers -> {tot_a} anchors) x {reps} per round"
             os.unlink(path)

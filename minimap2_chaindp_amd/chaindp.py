@@ -325,6 +325,13 @@ class Device:
         self._lib.chaindp_debug_deep_units.argtypes = [C.c_void_p]
         return int(self._lib.chaindp_debug_deep_units(self._ctx))
 
+    def set_twin_handover(self, mode=0):
+        """Test hook: what k_chain_twin hands over to k_chain_units whatever the units look like -- 0 nothing extra, 1 every unit
+        untouched, 2 every unit after its first 64-anchor tile (k_chain_units resumes behind the flushed tiles)."""
+        self._lib.chaindp_debug_set_twin_handover.restype = C.c_int
+        self._lib.chaindp_debug_set_twin_handover.argtypes = [C.c_void_p, C.c_int]
+        self._check(self._lib.chaindp_debug_set_twin_handover(self._ctx, int(mode)))
+
     def set_deep_handover(self, on=True):
         """Test hook: False keeps every unit in the launch that took it (k_chain_units then serves long scans from HBM/L2); 2 hands
         over any unit with a few deep scans, whatever its length, to k_chain_dense, 3 to k_chain_dense1 (small test inputs reach

@@ -43,7 +43,8 @@ struct chaindp_ctx {
 	int deep_route = 0;                   // test hook: 1 k_chain_dense, 2 k_chain_dense1 whatever the batch looks like
 	int deep_eager = 0;                   // test hook: hand over any unit with a few deep scans, whatever its length
 	bool deep_handover = true;            // CHAINDP_NO_DEEP_HANDOVER (diagnostic / A-B): every unit stays in the launch that took it
-	bool twin_force_left = false;         // CHAINDP_TWIN_FORCE_LEFT (tests): k_chain_twin hands every unit over; read once, at chaindp_create
+	int twin_force_left = 0;              // CHAINDP_TWIN_FORCE_LEFT / chaindp_debug_set_twin_handover (tests): 1 k_chain_twin hands every unit
+	                                      // over untouched, 2 after its first tile (k_chain_units resumes there); the variable is read once, at chaindp_create
 	int variant = 0;                      // 0: k_chain_twin + k_chain_units for the rest; 1: k_chain_units, general variant; 2: k_chain_units only
 	unsigned long long *d_counters = nullptr;
 	chaindp::PrepassScratch pre = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -190,7 +191,7 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.block_reads, blocks_bytes);   // 8 B per block, like the counters
 	ctx->cmp.block_reads = ctx->pre.block_reads;
 	ctx->deep_handover = getenv("CHAINDP_NO_DEEP_HANDOVER") == nullptr;      // diagnostic switches are read here, once per context:
-	ctx->twin_force_left = getenv("CHAINDP_TWIN_FORCE_LEFT") != nullptr;     // never on the launch path (contexts run from several host threads)
+	if (const char *v = getenv("CHAINDP_TWIN_FORCE_LEFT")) ctx->twin_force_left = atoi(v) == 2 ? 2 : 1;   // never on the launch path (contexts run from several host threads)
 	if (e != hipSuccess) {
 		g_create_error = std::string("chaindp_create: ") + hipGetErrorString(e);
 		chaindp_destroy(ctx);
@@ -273,7 +274,7 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		// (first_child[] is initialised by the DP kernels themselves, per tile: no batch-wide memset)
 		HIP_TRY(ctx, chaindp::launch_chain_twin(st, q, total / 2, d_off, d_a, ctx->d_sumq, lut, lut_stride, ctx->d_units, ctx->d_counters,
 		                                        d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->d_left, (unsigned int*)ctx->d_left_cnt,
-		                                        ctx->twin_force_left ? 1 : 0, total, ctx->d_unit_aux));
+		                                        ctx->twin_force_left, total, ctx->d_unit_aux));
 		const int64_t left_grid = total / 2 < 32768 ? total / 2 : 32768;
 		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, left_grid, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_left,
 		                                   ctx->d_left_cnt, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
@@ -606,6 +607,15 @@ extern "C" int64_t chaindp_debug_leftover(chaindp_ctx_t *ctx)
 	    hipMemcpy(&c, ctx->d_left_cnt, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess ||
 	    hipMemcpy(&cnt, ctx->d_counters, sizeof(cnt), hipMemcpyDeviceToHost) != hipSuccess) return -1;
 	return (uint32_t)c == 0xffffffffu ? (int64_t)(uint32_t)cnt : (int64_t)(uint32_t)c;
+}
+
+// test hook (not in the public header): what k_chain_twin hands over whatever the units look like -- 0 nothing extra, 1 every unit
+// untouched, 2 every unit after its first 64-anchor tile (k_chain_units resumes behind it)
+extern "C" int chaindp_debug_set_twin_handover(chaindp_ctx_t *ctx, int mode)
+{
+	if (!ctx || mode < 0 || mode > 2) return CHAINDP_ERR_ARG;
+	ctx->twin_force_left = mode;
+	return CHAINDP_OK;
 }
 
 // test hook (not in the public header): 0 keeps every unit in the launch that took it (the deep path of the small rings stays

@@ -483,8 +483,11 @@ anchor_done:
 	}
 }
 
+// resume > 0 (a multiple of 64): the unit's anchors [0, resume) are done -- k_chain_twin scored and flushed them before it handed the
+// unit over -- and this wave goes on from there: the ring gets their last RING entries back from a, f, p, v in HBM.  (Marks are per
+// scan, so nothing else carries over.)
 template <int RING, bool SAMEGAP>
-__device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
+__device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room, int resume = 0)
 {
 	typedef FastLds<RING> L;
 	constexpr int MASK = RING - 1;
@@ -502,7 +505,18 @@ __device__ __forceinline__ void run_unit_fast(const UnitCtx &c, int64_t room)
 	k.max_skip = c.max_skip;
 	k.ms0 = c.max_skip > 0 ? c.max_skip : 0;
 	uint64_t x_carry = 0;
-	for (int tile0 = 0;; tile0 += 64) {
+	if (resume > 0) {
+		for (int j = resume - RING + lane; j < resume; j += 64) if (j >= 0) {
+			const ulonglong2 aj = c.a[c.base + j];
+			const int pj = c.p[c.base + j];                            // stored read-relative, -1 = none
+			lds_store_b128(((uint32_t)(j & MASK) << 4), make_uint4((uint32_t)aj.x + 1u, (uint32_t)aj.y + 1u, (uint32_t)c.f[c.base + j],
+			                                                       pj < 0 ? 0xfffffffcu : (uint32_t)(pj - c.rel0) << 2));
+			lds_store_b32(L::V_OFF + ((uint32_t)(j & MASK) << 2), c.v[c.base + j]);
+		}
+		x_carry = c.a[c.base + resume - 1].x;                          // (the same address in every lane)
+		wave_mem_fence();
+	}
+	for (int tile0 = resume;; tile0 += 64) {
 		const int64_t gi = c.base + tile0 + lane;
 		const bool have = tile0 + lane < room;
 		ulonglong2 an = make_ulonglong2(0, 0);
@@ -599,7 +613,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 	// in the prepass' (longest first) order"
 	if (units_all && (uint32_t)counters[0] == 0xffffffffu) { units = units_all; n_units = (int64_t)(uint32_t)counters_all[0]; }
 	for (int64_t ub = blockIdx.x; ub < n_units; ub += gridDim.x) {
-		const Unit u = units[ub];
+		Unit u = units[ub];
+		// a unit k_chain_twin handed over after it had flushed some of its tiles carries that many anchors in the high word of its
+		// start (anchor indices fit 31 bits): the table-driven variant goes on from there instead of starting over
+		const int resume = (int)((uint64_t)u.start >> 32);
+		u.start = (int64_t)((uint64_t)u.start & 0xffffffffull);
 		const int64_t rs = off[u.read], re = off[u.read + 1];
 		const unsigned long long sq = sumq[u.read];
 		const int n_segs = n_segs_pr ? n_segs_pr[u.read] : par.n_segs;
@@ -622,8 +640,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 		wave_mem_fence();
 		// u.len bounds the unit (next unit's start or the read's end); run_unit finds the true end at the first gap
 		if (general) run_unit<RING>(c, (int64_t)u.len);
-		else if (par.max_dist_y >= par.max_dist_x) run_unit_fast<RING, true>(c, (int64_t)u.len);
-		else run_unit_fast<RING, false>(c, (int64_t)u.len);
+		else if (par.max_dist_y >= par.max_dist_x) run_unit_fast<RING, true>(c, (int64_t)u.len, resume);
+		else run_unit_fast<RING, false>(c, (int64_t)u.len, resume);
 	}
 }
 

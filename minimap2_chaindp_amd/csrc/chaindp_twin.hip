@@ -213,7 +213,7 @@ struct TwinArgs {
 	Unit *left;                       // leftover list for k_chain_units
 	unsigned int *left_cnt;
 	unsigned int *queue;              // next unit nobody has taken yet (the halves' first chunks are dealt statically: it starts behind them)
-	int force_left;                   // test switch: hand every unit over
+	int force_left;                   // test switch: 1 hand every unit over untouched, 2 hand every unit over after its first tile (resumed there)
 	int64_t total;                    // anchors of the batch
 	unsigned long long *stamp;        // diagnostic run (CHAINDP_TWIN_STAMP): per block 8 counters; nullptr otherwise
 };
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 		return;
 	}
 	const bool params_ok = g.lut != nullptr && !g.par.is_cdna && g.par.max_dist_x >= 1 && g.par.max_dist_y >= 0 &&
-	                       ((uint64_t)(int64_t)g.par.max_dist_x + 1) * 129ull < (1ull << 31) && g.par.bw + 1 <= (int)TW_LUT_HALF && !g.force_left;
+	                       ((uint64_t)(int64_t)g.par.max_dist_x + 1) * 129ull < (1ull << 31) && g.par.bw + 1 <= (int)TW_LUT_HALF && g.force_left != 1;
 
 	TwinHot u;
 	u.S = 0; u.m4 = 0; u.pc = curbase; u.pend = curbase;
@@ -412,10 +412,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 
 			// ---- the unit goes on?
 			bool goes_on = cnt_prev == TW_TILE && c_tile0 + TW_TILE < c_room;
-			if (goes_on && slow_h * 8 > c_tile0 + TW_TILE) {
-				// a unit that keeps needing second chunks (more than one anchor in eight) is cheaper in k_chain_units: hand the rest
-				// of it -- that is, all of it, from scratch -- over
-				if (lane == 0) { Unit un; un.start = c_base; un.read = c_read; un.len = c_room; g.left[atomicAdd(g.left_cnt, 1u)] = un; }
+			if (goes_on && (slow_h * 8 > c_tile0 + TW_TILE || g.force_left == 2)) {
+				// a unit that keeps needing second chunks (more than one anchor in eight) is cheaper in k_chain_units: hand the rest of
+				// it over.  The tiles up to the one flushed below are done: k_chain_units goes on behind them (the count rides in the
+				// high word of the start; force_left == 2 is the tests' way to send every unit down this road)
+				if (lane == 0) {
+					Unit un; un.start = (int64_t)((uint64_t)c_base | (uint64_t)(uint32_t)(c_tile0 + TW_TILE) << 32); un.read = c_read; un.len = c_room;
+					g.left[atomicAdd(g.left_cnt, 1u)] = un;
+				}
 				goes_on = false;
 			}
 			if (goes_on) {
@@ -595,8 +599,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 				wave_mem_fence();
 				if (hl == 0) {
 					const TwinCold c = TW_COLD;
-					Unit un; un.start = c.base; un.read = c.read; un.len = c.room;
-					g.left[atomicAdd(g.left_cnt, 1u)] = un;                  // the unit is over for this kernel: an empty tile ...
+					Unit un; un.start = (int64_t)((uint64_t)c.base | (uint64_t)(uint32_t)c.tile0 << 32); un.read = c.read; un.len = c.room;
+					g.left[atomicAdd(g.left_cnt, 1u)] = un;                  // k_chain_units goes on from the tile this scan is in (the tiles
+					                                                         // before it are flushed).  The unit is over for this kernel: an empty tile ...
 				}
 				u.pc = curbase; u.pend = curbase;                            // ... has nothing to flush and cannot go on: service() picks the half's next unit
 			}

@@ -113,6 +113,34 @@ def test_zero_and_mixed_q_spans(dev, variant):
         assert dev.leftover_units() > 0                    # the reads with a zero span went to k_chain_units
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["untouched", "resumed_after_first_tile"])
+@pytest.mark.parametrize("gen,preset,n_reads", [("ava-ont", "ava-ont", 200), ("map-ont", "map-ont", 60), ("ties", "map-ont", 120), ("skew", "ava-ont", 60)])
+def test_units_handed_over_by_the_twin_kernel(dev, gen, preset, n_reads, mode):
+    """What k_chain_twin hands to k_chain_units: a unit it never touched is done from scratch, a unit it gave up on (a scan past its
+    ring, too many second chunks) is RESUMED behind the tiles it had flushed -- the ring rebuilt from a, f, p, v.  The test hook
+    sends every unit down one road or the other; results must not depend on who scored which tile."""
+    dev.set_ring(128)
+    dev.set_variant(0)
+    dev.set_twin_handover(mode)
+    try:
+        par = P.preset(preset)
+        off, a = ag.generate(gen, n_reads=n_reads, seed=2024)
+        f, p, v = dev.chain_batch(par, off, a)
+        left = dev.leftover_units()
+        of, op, ov, _ = ol.oracle_batch(par, off, a, threads=8)
+        for name, x, y in (("f", f, of), ("p", p, op), ("v", v, ov)):
+            bad = np.flatnonzero(x != y)
+            assert bad.size == 0, (gen, mode, name, "first mismatch at anchor", int(bad[0]), int(x[bad[0]]), int(y[bad[0]]))
+        assert left > 0, (gen, mode)
+        soff, seeds = dev.compact(par)
+        for r in range(0, n_reads, max(1, n_reads // 20)):
+            lo, hi = int(off[r]), int(off[r + 1])
+            exp = ol.oracle_compact(par, np.ascontiguousarray(a[lo:hi]), of[lo:hi].copy(), op[lo:hi].copy(), ov[lo:hi].copy())
+            assert seeds[int(soff[r]):int(soff[r + 1])].tobytes() == exp.tobytes(), (gen, mode, r)
+    finally:
+        dev.set_twin_handover(0)
+
+
 def test_general_variant_on_seeded_batches(dev):
     dev.set_ring(256)
     dev.set_variant(True)
