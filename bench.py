@@ -191,6 +191,9 @@ def main():
         if "pair_evals_per_anchor" in extras:
             out["pair_evals_per_s"] = value * extras["pair_evals_per_anchor"]
         st_pmc = stored_pmc_any()
+        sp = stored_pmc(total)
+        if sp is not None and sp.get("scaled_from_anchors"):
+            out["roofline"]["traffic_scaled_from_anchors"] = sp["scaled_from_anchors"]      # per-anchor counters of the same build's N=1 profile
         if out["roofline"]["traffic"] is None and st_pmc is not None:
             # the stored counters belong to another build of the kernels or another batch: say so instead of a silent null
             out["roofline"]["traffic_stale"] = True
@@ -589,13 +592,26 @@ def stored_pmc_any():
 
 
 def stored_pmc(anchors_per_launch):
-    """PMC figures of the DP kernel from tools/profile.sh on this same workload (profiles/latest_traffic.json).  PMC collection
-    cannot run inside the timed process, so they are quoted only if they were measured on THIS build of the kernels (hash of
-    their sources) and this batch size; otherwise None."""
+    """PMC figures of the DP kernel from tools/profile.sh (profiles/latest_traffic.json).  PMC collection cannot run inside the timed
+    process, so they are quoted only if they were measured on THIS build of the kernels (hash of their sources); for another batch
+    size of the same workload (a rank's share of the job at N > 1) the per-anchor figures of that profile are scaled to the batch,
+    and the record says so (`scaled_from_anchors`).  Otherwise None."""
+    t = stored_pmc_any()
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
-        if t.get("anchors_per_launch") == anchors_per_launch and t.get("kernel_source_sha16") == kernel_source_sha16():
+        if not t or t.get("kernel_source_sha16") != kernel_source_sha16():
+            return None
+        n0 = t.get("anchors_per_launch")
+        if n0 == anchors_per_launch:
             return t
+        if n0 and anchors_per_launch > 0:
+            k = anchors_per_launch / n0
+            u = dict(t)
+            for key in ("hbm_read_bytes", "hbm_write_bytes", "hbm_bytes_per_launch", "valu_insts_per_launch", "salu_insts_per_launch", "lds_insts_per_launch"):
+                if u.get(key) is not None:
+                    u[key] = u[key] * k
+            u["anchors_per_launch"] = anchors_per_launch
+            u["scaled_from_anchors"] = n0
+            return u
     except Exception:  # noqa: BLE001
         pass
     return None
