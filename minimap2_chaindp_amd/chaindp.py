@@ -325,6 +325,18 @@ class Device:
         self._lib.chaindp_debug_deep_units.argtypes = [C.c_void_p]
         return int(self._lib.chaindp_debug_deep_units(self._ctx))
 
+    def set_quad(self, on=True):
+        """Test / A-B hook: let k_chain_quad (four units per wave; off by default: measured slower) take the batches it can."""
+        self._lib.chaindp_debug_set_quad.restype = C.c_int
+        self._lib.chaindp_debug_set_quad.argtypes = [C.c_void_p, C.c_int]
+        self._check(self._lib.chaindp_debug_set_quad(self._ctx, int(bool(on))))
+
+    def quad_took(self):
+        """True if k_chain_quad took the last batch (test hook)."""
+        self._lib.chaindp_debug_quad_took.restype = C.c_int
+        self._lib.chaindp_debug_quad_took.argtypes = [C.c_void_p]
+        return int(self._lib.chaindp_debug_quad_took(self._ctx)) == 1
+
     def set_twin_handover(self, mode=0):
         """Test hook: what k_chain_twin hands over to k_chain_units whatever the units look like -- 0 nothing extra, 1 every unit
         untouched, 2 every unit after its first 64-anchor tile (k_chain_units resumes behind the flushed tiles)."""

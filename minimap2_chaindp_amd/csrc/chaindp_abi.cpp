@@ -38,11 +38,14 @@ struct chaindp_ctx {
 	Unit *d_units = nullptr;
 	chaindp::UnitAux *d_unit_aux = nullptr;   // per unit, beside d_units: what k_chain_twin needs to pick it up without further loads
 	Unit *d_left = nullptr;               // units the two-per-wave kernel hands over to k_chain_units
-	unsigned long long *d_left_cnt = nullptr;   // [0] handed-over count | the twin kernel's queue << 32; [1] count of d_deep; [2] k_chain_dense1's two queues
+	unsigned long long *d_left_cnt = nullptr;   // [0] handed-over count | the twin / quad kernel's queue << 32; [1] count of d_deep; [2] k_chain_dense1's two queues;
+	                                            // [3] route: 1 = k_chain_quad took the batch
 	Unit *d_deep = nullptr;               // units k_chain_units hands over to its k_chain_dense (scans that keep reaching past the ring)
 	int deep_route = 0;                   // test hook: 1 k_chain_dense, 2 k_chain_dense1 whatever the batch looks like
 	int deep_eager = 0;                   // test hook: hand over any unit with a few deep scans, whatever its length
 	bool deep_handover = true;            // CHAINDP_NO_DEEP_HANDOVER (diagnostic / A-B): every unit stays in the launch that took it
+	bool use_quad = false;                // CHAINDP_QUAD=1 / chaindp_debug_set_quad (A/B, tests): one-table batches of ordinary units four per wave
+	                                      // (k_chain_quad: correct, measured slower than k_chain_twin -- DESIGN.md section 6 -- so off by default)
 	int twin_force_left = 0;              // CHAINDP_TWIN_FORCE_LEFT / chaindp_debug_set_twin_handover (tests): 1 k_chain_twin hands every unit
 	                                      // over untouched, 2 after its first tile (k_chain_units resumes there); the variable is read once, at chaindp_create
 	int variant = 0;                      // 0: k_chain_twin + k_chain_units for the rest; 1: k_chain_units, general variant; 2: k_chain_units only
@@ -175,7 +178,7 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_unit_aux, (na / 2 + 1) * sizeof(chaindp::UnitAux));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 2 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left, (na / 2 + 1) * sizeof(Unit));
-	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left_cnt, 3 * sizeof(unsigned long long));
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_left_cnt, 4 * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_deep, (na / 64 + 2) * sizeof(Unit));    // a unit is handed over after its first 64-anchor tile at the earliest (test mode), with anchors to go
 	size_t flags_bytes0 = 0, cblocks_bytes0 = 0;
 	chaindp::compact_scratch_bytes(ctx->cap_anchors, &flags_bytes0, &cblocks_bytes0);
@@ -187,9 +190,11 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.block_cnt, blocks_bytes);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.tile_tmp, blocks_bytes);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.units_tmp, (na / 2 + 1) * sizeof(Unit));
-	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.hist, 2 * 128 * sizeof(unsigned int));
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.hist, (2 * 128 + 2) * sizeof(unsigned int));
+	ctx->pre.key_range = ctx->pre.hist ? ctx->pre.hist + 2 * 128 : nullptr;
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.block_reads, blocks_bytes);   // 8 B per block, like the counters
 	ctx->cmp.block_reads = ctx->pre.block_reads;
+	ctx->use_quad = getenv("CHAINDP_QUAD") != nullptr;
 	ctx->deep_handover = getenv("CHAINDP_NO_DEEP_HANDOVER") == nullptr;      // diagnostic switches are read here, once per context:
 	if (const char *v = getenv("CHAINDP_TWIN_FORCE_LEFT")) ctx->twin_force_left = atoi(v) == 2 ? 2 : 1;   // never on the launch path (contexts run from several host threads)
 	if (e != hipSuccess) {
@@ -266,15 +271,21 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		HIP_TRY(ctx, hipMemsetAsync(ctx->d_tg, 0, (size_t)ctx->cap_anchors * 8, st));
 		ctx->epoch = 1;
 	}
-	HIP_TRY(ctx, hipMemsetAsync(ctx->d_left_cnt, 0, 3 * sizeof(unsigned long long), st));
+	HIP_TRY(ctx, hipMemsetAsync(ctx->d_left_cnt, 0, 4 * sizeof(unsigned long long), st));
 	Unit *const deep = ctx->deep_handover ? ctx->d_deep : nullptr;
 	unsigned int *const deep_cnt = (unsigned int*)(ctx->d_left_cnt + 1);
 	if (ctx->variant == 0 && lut && d_n_segs == nullptr) {
 		// ordinary units two per wave; what that kernel hands over (and nothing else) goes through k_chain_units
 		// (first_child[] is initialised by the DP kernels themselves, per tile: no batch-wide memset)
+		// four units per wave where the whole batch has one cost table, else two per wave: both are launched, the device decides
+		unsigned int *const route = (unsigned int*)(ctx->d_left_cnt + 3);
+		if (ctx->use_quad)
+			HIP_TRY(ctx, chaindp::launch_chain_quad(st, q, total / 2, d_a, lut, lut_stride, ctx->d_units, ctx->d_unit_aux, ctx->d_counters, ctx->pre.key_range,
+			                                        d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->d_left, (unsigned int*)ctx->d_left_cnt,
+			                                        (unsigned int*)ctx->d_left_cnt + 1, route, ctx->twin_force_left, total));
 		HIP_TRY(ctx, chaindp::launch_chain_twin(st, q, total / 2, d_off, d_a, ctx->d_sumq, lut, lut_stride, ctx->d_units, ctx->d_counters,
 		                                        d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->d_left, (unsigned int*)ctx->d_left_cnt,
-		                                        ctx->twin_force_left, total, ctx->d_unit_aux));
+		                                        ctx->twin_force_left, total, ctx->d_unit_aux, route));
 		const int64_t left_grid = total / 2 < 32768 ? total / 2 : 32768;
 		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, left_grid, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_left,
 		                                   ctx->d_left_cnt, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,
@@ -607,6 +618,24 @@ extern "C" int64_t chaindp_debug_leftover(chaindp_ctx_t *ctx)
 	    hipMemcpy(&c, ctx->d_left_cnt, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess ||
 	    hipMemcpy(&cnt, ctx->d_counters, sizeof(cnt), hipMemcpyDeviceToHost) != hipSuccess) return -1;
 	return (uint32_t)c == 0xffffffffu ? (int64_t)(uint32_t)cnt : (int64_t)(uint32_t)c;
+}
+
+// test hook (not in the public header): 1 lets k_chain_quad take the batches it can (one cost table, ordinary units), 0 (default) never
+extern "C" int chaindp_debug_set_quad(chaindp_ctx_t *ctx, int on)
+{
+	if (!ctx) return CHAINDP_ERR_ARG;
+	ctx->use_quad = on != 0;
+	return CHAINDP_OK;
+}
+
+// test hook (not in the public header): 1 if k_chain_quad took the last batch
+extern "C" int chaindp_debug_quad_took(chaindp_ctx_t *ctx)
+{
+	if (!ctx || !ctx->d_left_cnt) return -1;
+	unsigned long long r = 0;
+	if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+	    hipMemcpy(&r, ctx->d_left_cnt + 3, sizeof(r), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	return (uint32_t)r != 0;
 }
 
 // test hook (not in the public header): what k_chain_twin hands over whatever the units look like -- 0 nothing extra, 1 every unit

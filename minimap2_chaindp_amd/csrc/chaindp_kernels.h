@@ -39,6 +39,7 @@ struct PrepassScratch {
 	Unit *units_tmp;                 // units in anchor order, before the longest-first scatter
 	unsigned int *hist;              // 2 x 128: length-class histogram / bases, cursors
 	int2 *block_reads;               // per 1024-anchor block: reads of its first and last anchor (also used by the compaction)
+	unsigned int *key_range;         // [0] smallest, [1] largest UnitAux::lutkey among the units k_chain_twin / k_chain_quad may take
 };
 size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *blocks_bytes);
 
@@ -90,8 +91,17 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
                              const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride, const Unit *d_units,
                              const unsigned long long *d_counters, int32_t *d_f, int32_t *d_p, int32_t *d_v,
                              int32_t *d_first_child, uint8_t *d_flags, Unit *d_left, unsigned int *d_left_cnt, int force_left, int64_t total,
-                             const UnitAux *d_unit_aux);
+                             const UnitAux *d_unit_aux, const unsigned int *d_route = nullptr);
 size_t twin_lds_bytes();
+
+// Four units per wave, 16 lanes each, two predecessors per lane (chaindp_quad.hip): takes a batch of ordinary units whose reads all
+// have the same cost table (key_range: PrepassScratch::key_range) and says so in *d_route; otherwise it leaves the batch to
+// launch_chain_twin, which is launched behind it and returns at once when *d_route is set.  Same hand-over list.
+hipError_t launch_chain_quad(hipStream_t st, const Params &par, int64_t max_units, const void *d_a, const uint16_t *d_lut, int lut_stride,
+                             const Unit *d_units, const UnitAux *d_unit_aux, const unsigned long long *d_counters, const unsigned int *d_key_range,
+                             int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags, Unit *d_left,
+                             unsigned int *d_left_cnt, unsigned int *d_queue, unsigned int *d_route, int force_left, int64_t total);
+size_t quad_lds_bytes();
 
 // exclusive scan of n uint64 items in place (d_tile_tmp: ceil(n/1024)+1 words), total to *d_total
 hipError_t launch_scan_u64(hipStream_t st, int64_t n, unsigned long long *d_data, unsigned long long *d_tile_tmp,

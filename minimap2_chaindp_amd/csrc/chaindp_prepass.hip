@@ -234,9 +234,10 @@ __global__ __launch_bounds__(256) void k_emit_units(int64_t n_reads, int64_t n_w
 }
 
 // hist[c] -> first position of class c in the longest-first order; cursor[c] = 0
-__global__ void k_unit_bases(unsigned int *__restrict__ hist, unsigned int *__restrict__ cursor)
+__global__ void k_unit_bases(unsigned int *__restrict__ hist, unsigned int *__restrict__ cursor, unsigned int *__restrict__ key_range)
 {
 	if (threadIdx.x == 0) {
+		if (key_range) { key_range[0] = 0xffffffffu; key_range[1] = 0u; }
 		unsigned int acc = 0;
 		for (int c = UNIT_CLASSES - 1; c >= 0; --c) { const unsigned int n = hist[c]; hist[c] = acc; acc += n; cursor[c] = 0; }
 	}
@@ -248,9 +249,13 @@ __global__ void k_unit_bases(unsigned int *__restrict__ hist, unsigned int *__re
 __global__ __launch_bounds__(256) void k_unit_scatter(const unsigned long long *__restrict__ counters, const Unit *__restrict__ in,
                                                       const unsigned int *__restrict__ base, unsigned int *__restrict__ cursor,
                                                       Unit *__restrict__ out, Params par, const int64_t *__restrict__ off,
-                                                      const unsigned long long *__restrict__ sumq, UnitAux *__restrict__ out_aux)
+                                                      const unsigned long long *__restrict__ sumq, UnitAux *__restrict__ out_aux,
+                                                      unsigned int *__restrict__ key_range)
 {
 	__shared__ unsigned int s_cnt[UNIT_CLASSES], s_base[UNIT_CLASSES];
+	__shared__ unsigned int s_kmin, s_kmax;
+	if (threadIdx.x == 0) { s_kmin = 0xffffffffu; s_kmax = 0u; }
+	unsigned int kmin = 0xffffffffu, kmax = 0u;                     // table keys of this thread's units that the two / four-per-wave kernels may take
 	const int64_t n = (int64_t)(uint32_t)counters[0];
 	const int64_t per_block = 256 * SCAT_PER_THREAD;
 	for (int64_t b0 = (int64_t)blockIdx.x * per_block; b0 < n; b0 += (int64_t)gridDim.x * per_block) {
@@ -283,9 +288,16 @@ __global__ __launch_bounds__(256) void k_unit_scatter(const unsigned long long *
 				ax.rel0 = (int32_t)(u[k].start - rs); ax.lutkey = __float_as_uint(avg);
 				ax.flags = ((sq & (SUMQ_SEG_FLAG | SUMQ_SPAN0_FLAG)) || lut16) ? 1u : 0u; ax.pad = 0;
 				out_aux[pos] = ax;
+				if (ax.flags == 0) { kmin = ax.lutkey < kmin ? ax.lutkey : kmin; kmax = ax.lutkey > kmax ? ax.lutkey : kmax; }   // (avg_qspan > 0: its bits order like integers)
 			}
 		}
 		__syncthreads();
+	}
+	if (key_range) {                                               // one pair of atomics per block (they all hit the same two words)
+		for (int d = 32; d; d >>= 1) { const unsigned int a = __shfl_xor(kmin, d, 64), b = __shfl_xor(kmax, d, 64); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+		if ((threadIdx.x & 63) == 0) { atomicMin(&s_kmin, kmin); atomicMax(&s_kmax, kmax); }
+		__syncthreads();
+		if (threadIdx.x == 0 && s_kmin <= s_kmax) { atomicMin(&key_range[0], s_kmin); atomicMax(&key_range[1], s_kmax); }
 	}
 }
 
@@ -332,9 +344,9 @@ hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, in
 	if ((e = hipMemsetAsync(sc.hist, 0, 2 * UNIT_CLASSES * sizeof(unsigned int), st)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_emit_units, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, n_reads, words, d_off,
 	                   sc.start_mask, sc.block_cnt, sc.units_tmp, sc.hist, sc.block_reads);
-	hipLaunchKernelGGL(k_unit_bases, dim3(1), dim3(64), 0, st, sc.hist, sc.hist + UNIT_CLASSES);
+	hipLaunchKernelGGL(k_unit_bases, dim3(1), dim3(64), 0, st, sc.hist, sc.hist + UNIT_CLASSES, d_unit_aux ? sc.key_range : nullptr);
 	hipLaunchKernelGGL(k_unit_scatter, dim3((unsigned)(blocks < 1024 ? (blocks > 0 ? blocks : 1) : 1024)), dim3(256), 0, st, d_counters, sc.units_tmp,
-	                   sc.hist, sc.hist + UNIT_CLASSES, d_units, par, d_off, d_sumq, d_unit_aux);
+	                   sc.hist, sc.hist + UNIT_CLASSES, d_units, par, d_off, d_sumq, d_unit_aux, d_unit_aux ? sc.key_range : nullptr);
 	return hipGetLastError();
 }
 

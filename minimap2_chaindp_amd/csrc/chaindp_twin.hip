@@ -41,6 +41,7 @@
 #include <vector>
 #include "chaindp_kernels.h"
 #include "chaindp_wave.h"
+#include "chaindp_lanes.h"
 
 namespace chaindp {
 
@@ -63,43 +64,6 @@ namespace chaindp {
 #define TW_TILE 64                      // anchors a half takes in / flushes at a time
 #define TW_RING 64                      // predecessors a scan can reach in this kernel (two chunks of 32)
 #define TW_QCH 8                        // units a half takes from the queue at a time
-
-#if defined(__HIP_DEVICE_COMPILE__)
-#define TW_LDS(T, a) ((__attribute__((address_space(3))) T*)(a))
-#else
-#define TW_LDS(T, a) ((T*)(uintptr_t)(a))          /* host pass of the single-source compile; never executed */
-#endif
-// unit records and their UnitAux are read through the scalar cache: a load from the constant address space with a wave-uniform
-// address is an s_load (the arrays are written by the prepass, never by this kernel)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define TW_CONST(T, p) ((const __attribute__((address_space(4))) T*)(uintptr_t)(p))
-#else
-#define TW_CONST(T, p) ((const T*)(p))
-#endif
-typedef uint32_t tw_u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t tw_u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ tw_u32x2 tw_ld64(uint32_t a) { return *TW_LDS(const tw_u32x2, a); }
-__device__ __forceinline__ int tw_ld32(uint32_t a) { return *TW_LDS(const int, a); }
-__device__ __forceinline__ int tw_ld_i8(uint32_t a) { return (int)*TW_LDS(const signed char, a); }
-__device__ __forceinline__ int tw_ld_u8(uint32_t a) { return (int)*TW_LDS(const unsigned char, a); }
-__device__ __forceinline__ tw_u32x4 tw_ld128(uint32_t a) { return *TW_LDS(const tw_u32x4, a); }
-__device__ __forceinline__ void tw_st64(uint32_t a, uint32_t x, uint32_t y) { tw_u32x2 t; t.x = x; t.y = y; *TW_LDS(tw_u32x2, a) = t; }
-__device__ __forceinline__ void tw_st32(uint32_t a, int v) { *TW_LDS(int, a) = v; }
-__device__ __forceinline__ void tw_st8(uint32_t a, int v) { *TW_LDS(signed char, a) = (signed char)v; }
-__device__ __forceinline__ void tw_st128(uint32_t a, uint32_t x, uint32_t y, uint32_t z, uint32_t w) { tw_u32x4 t; t.x = x; t.y = y; t.z = z; t.w = w; *TW_LDS(tw_u32x4, a) = t; }
-
-// keeps a value in a vector register: the compiler would otherwise hold wave-uniform values in SGPRs and feed them
-// to VALU instructions as scalar operands, which halves their issue rate
-#if defined(__HIP_DEVICE_COMPILE__)
-#define TW_VREG(x) asm volatile("" : "+v"(x))
-#else
-#define TW_VREG(x) ((void)(x))
-#endif
-
-// a lane mask is wave-uniform by construction; where the compiler's divergence analysis loses track of that (values merged
-// behind loops) this keeps it in scalar registers (folds away when it already is)
-#define TW_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 
 // exclusive prefix max over the 32 lanes of each half, floor 0 (scores are >= 0 where they matter): inclusive scan
 // inside the 16-lane rows (4 DPP steps), one-lane shift inside the rows, and for the upper row of each half the lower
@@ -171,16 +135,6 @@ __device__ __forceinline__ uint32_t tw_both_halves(uint64_t m)
 	return t;
 }
 
-// |a - b| + c in one instruction
-__device__ __forceinline__ uint32_t tw_sad(uint32_t a, uint32_t b, uint32_t c)
-{
-	uint32_t d = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-#endif
-	return d;
-}
-
 // per half: bits of m below the half's lowest set bit of b (all of m where b has none)
 __device__ __forceinline__ uint64_t tw_below_first(uint64_t m, uint64_t b)
 {
@@ -189,12 +143,6 @@ __device__ __forceinline__ uint64_t tw_below_first(uint64_t m, uint64_t b)
 	return m & ((uint64_t)khi << 32 | klo);
 }
 
-// lane masks straight from a vector compare (v_cmp_*_e64 into an SGPR pair, no bool in between)
-#define TW_ULT(a, b) __builtin_amdgcn_uicmp((unsigned)(a), (unsigned)(b), 36)
-#define TW_EQ(a, b)  __builtin_amdgcn_uicmp((unsigned)(a), (unsigned)(b), 32)
-#define TW_SGT(a, b) __builtin_amdgcn_sicmp((int)(a), (int)(b), 38)
-#define TW_SGE(a, b) __builtin_amdgcn_sicmp((int)(a), (int)(b), 39)
-#define TW_SEL(m, a, b) (__builtin_amdgcn_inverse_ballot_w64(m) ? (a) : (b))
 #define TW_HI31 0x8000000080000000ull
 
 struct TwinArgs {
@@ -213,6 +161,7 @@ struct TwinArgs {
 	Unit *left;                       // leftover list for k_chain_units
 	unsigned int *left_cnt;
 	unsigned int *queue;              // next unit nobody has taken yet (the halves' first chunks are dealt statically: it starts behind them)
+	const unsigned int *route;        // *route != 0: k_chain_quad (launched in front of this kernel) has taken the batch
 	int force_left;                   // test switch: 1 hand every unit over untouched, 2 hand every unit over after its first tile (resumed there)
 	int64_t total;                    // anchors of the batch
 	unsigned long long *stamp;        // diagnostic run (CHAINDP_TWIN_STAMP): per block 8 counters; nullptr otherwise
@@ -296,6 +245,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 	TW_VREG(c_ms); TW_VREG(c_min); TW_VREG(c_Mout); TW_VREG(c_bwl); TW_VREG(c_cbwl);
 
 	const uint64_t maxx = (uint64_t)(int64_t)g.par.max_dist_x;
+	if (g.route && *g.route) return;                               // (uniform) the batch went four units per wave
 	const int64_t n_units = (int64_t)(uint32_t)g.counters[0];
 	// the kernel's 32-bit differences (and the signed window test) are exact while 129 * (max_dist_x + 1) < 2^31
 	// Units of a few thousand anchors (map-ont shape) are few and each is a long serial chain: two of them side by side gain
@@ -757,7 +707,7 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
                              const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride, const Unit *d_units,
                              const unsigned long long *d_counters, int32_t *d_f, int32_t *d_p, int32_t *d_v,
                              int32_t *d_first_child, uint8_t *d_flags, Unit *d_left, unsigned int *d_left_cnt, int force_left, int64_t total,
-                             const UnitAux *d_unit_aux)
+                             const UnitAux *d_unit_aux, const unsigned int *d_route)
 {
 	if (max_units <= 0) return hipSuccess;
 	if (!d_unit_aux) return hipErrorInvalidValue;
@@ -776,7 +726,7 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
 	TwinArgs g;
 	g.par = par; g.off = d_off; g.a = (const ulonglong2*)d_a; g.sumq = d_sumq; g.lut = d_lut; g.lut_stride = lut_stride;
 	g.units = d_units; g.aux = d_unit_aux; g.counters = d_counters; g.f = d_f; g.p = d_p; g.v = d_v; g.first_child = d_first_child; g.flags = d_flags;
-	g.left = d_left; g.left_cnt = d_left_cnt; g.queue = d_left_cnt + 1; g.force_left = force_left; g.total = total;
+	g.left = d_left; g.left_cnt = d_left_cnt; g.queue = d_left_cnt + 1; g.route = d_route; g.force_left = force_left; g.total = total;
 	// diagnostic: CHAINDP_TWIN_STAMP=1 makes the kernel stamp where its waves' time goes (s_memtime: shader-clock ticks) and this
 	// function print the averages -- it synchronises, so never set it in a timed run
 	static unsigned long long *d_stamp = nullptr;

@@ -141,6 +141,36 @@ def test_units_handed_over_by_the_twin_kernel(dev, gen, preset, n_reads, mode):
         dev.set_twin_handover(0)
 
 
+@pytest.mark.parametrize("mode", [0, 2], ids=["plain", "handover_after_first_tile"])
+@pytest.mark.parametrize("gen,gen_over,preset,n_reads", [("ava-ont", {}, "ava-ont", 300), ("skew", dict(skew_max=30000), "ava-ont", 100),
+                                                        ("ava-ont", dict(q_span=31, span_jitter=0), "ava-ont", 40), ("ava-ont", dict(noise_pct=40, tie_pct=20), "ava-ont", 120)])
+def test_four_units_per_wave_variant(dev, gen, gen_over, preset, n_reads, mode):
+    """k_chain_quad (chaindp_quad.hip: four units per wave, two predecessors per lane; off by default because it measured slower than
+    k_chain_twin) takes batches whose reads all have one cost table: same results, element for element -- also when every unit is
+    handed to k_chain_units after its first tile, and on a noisy shape whose scans interleave new maxima and marked predecessors."""
+    dev.set_ring(128)
+    dev.set_variant(0)
+    dev.set_quad(True)
+    dev.set_twin_handover(mode)
+    try:
+        par = P.preset(preset)
+        off, a = ag.generate(gen, n_reads=n_reads, seed=99, **gen_over)
+        f, p, v = dev.chain_batch(par, off, a)
+        assert dev.quad_took()
+        of, op, ov, _ = ol.oracle_batch(par, off, a, threads=8)
+        for name, x, y in (("f", f, of), ("p", p, op), ("v", v, ov)):
+            bad = np.flatnonzero(x != y)
+            assert bad.size == 0, (gen, mode, name, "first mismatch at anchor", int(bad[0]), int(x[bad[0]]), int(y[bad[0]]))
+        soff, seeds = dev.compact(par)
+        for r in range(0, n_reads, max(1, n_reads // 15)):
+            lo, hi = int(off[r]), int(off[r + 1])
+            exp = ol.oracle_compact(par, np.ascontiguousarray(a[lo:hi]), of[lo:hi].copy(), op[lo:hi].copy(), ov[lo:hi].copy())
+            assert seeds[int(soff[r]):int(soff[r + 1])].tobytes() == exp.tobytes(), (gen, mode, r)
+    finally:
+        dev.set_quad(False)
+        dev.set_twin_handover(0)
+
+
 def test_general_variant_on_seeded_batches(dev):
     dev.set_ring(256)
     dev.set_variant(True)
