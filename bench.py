@@ -579,7 +579,7 @@ def measure_pipelined(torch, chaindp, dev_index, par, off, anchors, total, pagea
 def kernel_source_sha16():
     import hashlib
     h = hashlib.sha256()
-    for f in ("chaindp_twin.hip", "chaindp_kernels.hip", "chaindp_fast.h", "chaindp_wave.h"):
+    for f in ("chaindp_twin.hip", "chaindp_kernels.hip", "chaindp_fast.h", "chaindp_wave.h", "chaindp_lanes.h"):
         h.update(open(os.path.join(ROOT, "minimap2_chaindp_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

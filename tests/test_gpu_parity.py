@@ -143,7 +143,7 @@ def test_units_handed_over_by_the_twin_kernel(dev, gen, preset, n_reads, mode):
 
 @pytest.mark.parametrize("mode", [0, 2], ids=["plain", "handover_after_first_tile"])
 @pytest.mark.parametrize("gen,gen_over,preset,n_reads", [("ava-ont", {}, "ava-ont", 300), ("skew", dict(skew_max=30000), "ava-ont", 100),
-                                                        ("ava-ont", dict(q_span=31, span_jitter=0), "ava-ont", 40), ("ava-ont", dict(noise_pct=40, tie_pct=20), "ava-ont", 120)])
+                                                        ("ava-ont", dict(q_span=21, span_jitter=0), "ava-ont", 40), ("ava-ont", dict(noise_pct=40, tie_pct=20), "ava-ont", 120)])
 def test_four_units_per_wave_variant(dev, gen, gen_over, preset, n_reads, mode):
     """k_chain_quad (chaindp_quad.hip: four units per wave, two predecessors per lane; off by default because it measured slower than
     k_chain_twin) takes batches whose reads all have one cost table: same results, element for element -- also when every unit is

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def kernel_source_sha16():
     """Hash of the chain DP kernels' sources: bench.py only quotes stored PMC figures for the build they were measured on."""
     h = hashlib.sha256()
-    for f in ("chaindp_twin.hip", "chaindp_kernels.hip", "chaindp_fast.h", "chaindp_wave.h"):
+    for f in ("chaindp_twin.hip", "chaindp_kernels.hip", "chaindp_fast.h", "chaindp_wave.h", "chaindp_lanes.h"):
         h.update(open(os.path.join(ROOT, "minimap2_chaindp_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
