@@ -61,7 +61,7 @@ struct chaindp_ctx {
 	size_t lut_bytes = 0;
 	bool use_lut = true;
 	// compaction (allocated on first use)
-	int32_t *d_first_child = nullptr, *d_id = nullptr;
+	int32_t *d_first_child = nullptr;
 	int64_t *d_seeds_off = nullptr;
 	void *d_seeds = nullptr;
 	// seed collection (allocated on first use, grown with the batch)
@@ -140,7 +140,7 @@ extern "C" void chaindp_destroy(chaindp_ctx_t *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	for (auto &es : ctx->pending) for (int k = 0; k < es.n; ++k) (void)hipEventDestroy(es.e[k]);
 	void *bufs[] = {ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_sumq, ctx->d_units,
-	                ctx->d_counters, ctx->d_unit_aux, ctx->d_left, ctx->d_left_cnt, ctx->d_deep, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->pre.units_tmp, ctx->pre.hist, ctx->pre.block_reads, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->cmp.sub, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds};
+	                ctx->d_counters, ctx->d_unit_aux, ctx->d_left, ctx->d_left_cnt, ctx->d_deep, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->pre.units_tmp, ctx->pre.hist, ctx->pre.block_reads, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->cmp.sub, ctx->d_first_child, ctx->d_seeds_off, ctx->d_seeds};
 	for (void *b : bufs) if (b) (void)hipFree(b);
 	for (void *b : ctx->bot_allocs) if (b) (void)hipFree(b);
 	void *sbufs[] = {ctx->seed.kept, ctx->seed.used, ctx->seed.src, ctx->seed.mstate, ctx->seed.tile_tmp, ctx->seed.totals, ctx->seed.stacks,
@@ -395,19 +395,19 @@ static int compact_launch(chaindp_ctx *ctx, const chaindp_params_t *par)
 		const size_t na = (size_t)ctx->cap_anchors, nr = (size_t)ctx->cap_reads;
 		size_t flags_bytes = 0, blocks_bytes = 0;
 		chaindp::compact_scratch_bytes(ctx->cap_anchors, &flags_bytes, &blocks_bytes);
-		void *nb[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-		const size_t sz[7] = {na * 4, (nr + 1) * 8, ctx->d_seeds ? 0 : na * sizeof(chaindp_seed_t) + 16, blocks_bytes, blocks_bytes, 8, blocks_bytes * 16};
+		void *nb[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+		const size_t sz[6] = {(nr + 1) * 8, ctx->d_seeds ? 0 : na * sizeof(chaindp_seed_t) + 16, blocks_bytes, blocks_bytes, 8, blocks_bytes * 32};
 		hipError_t e = hipSuccess;
-		for (int k = 0; k < 7 && e == hipSuccess; ++k) if (sz[k]) e = hipMalloc(&nb[k], sz[k]);
+		for (int k = 0; k < 6 && e == hipSuccess; ++k) if (sz[k]) e = hipMalloc(&nb[k], sz[k]);
 		if (e != hipSuccess) {
 			for (void *b : nb) if (b) (void)hipFree(b);
 			ctx->err = std::string("compaction buffers: ") + hipGetErrorString(e);
 			return CHAINDP_ERR_HIP;
 		}
-		ctx->d_id = (int32_t*)nb[0]; ctx->d_seeds_off = (int64_t*)nb[1];
-		if (nb[2]) ctx->d_seeds = nb[2];                        // (seed collection may have made it already)
-		ctx->cmp.block_cnt = (unsigned long long*)nb[3]; ctx->cmp.tile_tmp = (unsigned long long*)nb[4];
-		ctx->cmp.n_seeds = (unsigned long long*)nb[5]; ctx->cmp.sub = (uint16_t*)nb[6];
+		ctx->d_seeds_off = (int64_t*)nb[0];
+		if (nb[1]) ctx->d_seeds = nb[1];                        // (seed collection may have made it already)
+		ctx->cmp.block_cnt = (unsigned long long*)nb[2]; ctx->cmp.tile_tmp = (unsigned long long*)nb[3];
+		ctx->cmp.n_seeds = (unsigned long long*)nb[4]; ctx->cmp.sub = (uint32_t*)nb[5];
 		ctx->compact_ready = true;
 	}
 	EventSet es; es.n = 0; es.slot0 = 2;
@@ -417,7 +417,7 @@ static int compact_launch(chaindp_ctx *ctx, const chaindp_params_t *par)
 		HIP_TRY(ctx, hipEventRecord(es.e[0], ctx->stream));
 	}
 	HIP_TRY(ctx, chaindp::launch_compact(ctx->stream, to_params(par), ctx->n_reads, ctx->total, ctx->d_off, ctx->d_a, ctx->d_f, ctx->d_p,
-	                                     ctx->d_v, ctx->d_first_child, ctx->d_id, ctx->d_seeds_off, ctx->d_seeds, ctx->cmp));
+	                                     ctx->d_v, ctx->d_first_child, ctx->d_seeds_off, ctx->d_seeds, ctx->cmp));
 	if (ctx->prof) { HIP_TRY(ctx, hipEventRecord(es.e[1], ctx->stream)); ctx->pending.push_back(es); }
 	return CHAINDP_OK;
 }

@@ -128,8 +128,8 @@ __device__ __forceinline__ void flag_or(uint4 &v, int e, unsigned int bits)
 __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t total,
                                                      const int64_t *__restrict__ off, const int32_t *__restrict__ p,
                                                      const int32_t *__restrict__ first_child,
-                                                     uint8_t *__restrict__ flags, unsigned long long *__restrict__ block_cnt,
-                                                     const int2 *__restrict__ block_reads, uint16_t *__restrict__ sub)
+                                                     const uint8_t *__restrict__ flags, unsigned long long *__restrict__ block_cnt,
+                                                     const int2 *__restrict__ block_reads, uint32_t *__restrict__ sub)
 {
 	const int lane = threadIdx.x & 63;
 	const int64_t blk0 = ((int64_t)blockIdx.x * (CMP_BLOCK / 64) + (threadIdx.x >> 6)) * CNT_BLOCKS_PER_WAVE;
@@ -163,20 +163,32 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t to
 		}
 		if (n < 16) cand &= ~(((1ull << (16 - n)) - 1ull) << (16 * b + n));
 	}
+	// two candidates per lane and trip: their loads (the read's start and p, then first_child) are in flight side by side
 	while (__builtin_amdgcn_ballot_w64(cand != 0)) {
-		if (cand) {
-			const int bit = __builtin_ctzll(cand);
-			cand &= cand - 1;
-			const int b = bit >> 4, e = bit & 15;
-			const int64_t ge = (blk0 + b) * CMP_PER_BLOCK + 16 * lane + e;
-			const int2 r2 = b == 0 ? rr[0] : b == 1 ? rr[1] : b == 2 ? rr[2] : rr[3];
-			const int64_t rs = off[r2.x == r2.y ? r2.x : read_of_c(off, r2.x, r2.y, ge)];
-			if (first_child[rs + p[ge]] == (int32_t)(ge - rs)) {
-				const unsigned int fl = (flag_word(b == 0 ? vv[0] : b == 1 ? vv[1] : b == 2 ? vv[2] : vv[3], e >> 2) >> (8 * (e & 3))) & 0xffu;
-				flags[ge] = (uint8_t)(fl | 1u);
-				if (b == 0) flag_or(vv[0], e, 1u); else if (b == 1) flag_or(vv[1], e, 1u); else if (b == 2) flag_or(vv[2], e, 1u); else flag_or(vv[3], e, 1u);
+		int bit[2];
+		int64_t ge[2] = {0, 0}, rs[2] = {0, 0};
+		int32_t pe[2] = {0, 0}, fc[2] = {0, 0};
+#pragma unroll
+		for (int c = 0; c < 2; ++c) {
+			bit[c] = -1;
+			if (cand) {
+				bit[c] = __builtin_ctzll(cand);
+				cand &= cand - 1;
+				const int b = bit[c] >> 4;
+				ge[c] = (blk0 + b) * CMP_PER_BLOCK + 16 * lane + (bit[c] & 15);
+				const int2 r2 = b == 0 ? rr[0] : b == 1 ? rr[1] : b == 2 ? rr[2] : rr[3];
+				rs[c] = off[r2.x == r2.y ? r2.x : read_of_c(off, r2.x, r2.y, ge[c])];
+				pe[c] = p[ge[c]];
 			}
 		}
+#pragma unroll
+		for (int c = 0; c < 2; ++c) if (bit[c] >= 0) fc[c] = first_child[rs[c] + pe[c]];
+#pragma unroll
+		for (int c = 0; c < 2; ++c)
+			if (bit[c] >= 0 && fc[c] == (int32_t)(ge[c] - rs[c])) {
+				const int b = bit[c] >> 4, e = bit[c] & 15;
+				if (b == 0) flag_or(vv[0], e, 1u); else if (b == 1) flag_or(vv[1], e, 1u); else if (b == 2) flag_or(vv[2], e, 1u); else flag_or(vv[3], e, 1u);
+			}
 	}
 #pragma unroll
 	for (int b = 0; b < CNT_BLOCKS_PER_WAVE; ++b) {
@@ -195,67 +207,19 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t to
 				mine += (unsigned int)__builtin_popcount(w & 0x03030303u);    // late + self per anchor
 			}
 		}
-		// records in front of each lane's 16 anchors inside the block: lets k_emit_seeds find the position of any anchor of an
-		// earlier block from block_base[] + this + at most 15 flag bytes
+		// records in front of each lane's 16 anchors inside the block (low half): lets k_emit_seeds find the position of any anchor
+		// of an earlier block from block_base[] + this + at most 15 flag bytes.  High half: the late bits of the lane's 16 anchors --
+		// flags[] itself is left as the DP kernels wrote it (a byte store per late anchor was a read-modify-write of a whole
+		// memory burst each: 1.1 GB of writes for 18 M late anchors on the 100k-read job, most of this kernel's time)
+		unsigned int late = 0;
+		for (int k = 0; k < 4; ++k) {
+			const unsigned int w = flag_word(vv[b], k) & 0x01010101u;
+			late |= ((w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u)) << (4 * k);
+		}
 		unsigned int incl = mine;
 		for (int d = 1; d < 64; d <<= 1) { const unsigned int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-		sub[blk * 64 + lane] = (uint16_t)(incl - mine);
+		sub[blk * 64 + lane] = (incl - mine) | late << 16;
 		if (lane == 63) block_cnt[blk] = incl;
-	}
-}
-
-// C3: positions.  block_base = exclusive scan of block_cnt.  Writes batch-global ids and seeds_off[r] at every
-// read's first anchor (empty reads in front of it share the value).  One wave per 1024-anchor block in four
-// passes of 256 anchors, 4 consecutive anchors per lane: the four flag loads are issued together, the id stores of
-// a pass are 1 KB contiguous per wave (16 anchors per lane would scatter 16-byte stores at a 64-byte stride).
-__global__ __launch_bounds__(CMP_BLOCK) void k_positions(int64_t n_reads, int64_t total, const int64_t *__restrict__ off,
-                                                         const int32_t *__restrict__ p, const uint8_t *__restrict__ flags,
-                                                         const unsigned long long *__restrict__ block_base,
-                                                         int32_t *__restrict__ id, int64_t *__restrict__ seeds_off,
-                                                         const int2 *__restrict__ block_reads)
-{
-	const int lane = threadIdx.x & 63;
-	const int64_t blk = (int64_t)blockIdx.x * (CMP_BLOCK / 64) + (threadIdx.x >> 6);
-	const int64_t g0 = blk * CMP_PER_BLOCK;
-	if (g0 >= total) return;
-	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
-	const int2 rr = block_reads[blk];
-	const int64_t rlo = rr.x, rhi = rr.y;
-	uint32_t w[4];
-	int n[4];
-	for (int it = 0; it < 4; ++it) {
-		const int64_t g = g0 + 256 * it + 4 * lane;
-		w[it] = 0; n[it] = 0;
-		if (g < g1) {
-			w[it] = *(const uint32_t*)(flags + g);                 // the array is padded to 16 B
-			n[it] = g1 - g < 4 ? (int)(g1 - g) : 4;
-			if (n[it] < 4) w[it] &= (1u << (8 * n[it])) - 1u;
-		}
-	}
-	unsigned int carry = (unsigned int)block_base[blk];
-	for (int it = 0; it < 4; ++it) {
-		const int64_t g = g0 + 256 * it + 4 * lane;
-		const unsigned int mine = (unsigned int)__builtin_popcount(w[it] & 0x03030303u);
-		unsigned int incl = mine;
-		for (int d = 1; d < 64; d <<= 1) { const unsigned int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-		unsigned int pos = carry + incl - mine;
-		carry += __shfl(incl, 63, 64);
-		if (n[it] == 0) continue;
-		if ((w[it] & 0x03030303u) == 0x02020202u && rlo == rhi && g != off[rlo]) {
-			*(int4*)(id + g) = make_int4((int)pos, (int)pos + 1, (int)pos + 2, (int)pos + 3);   // the common case: four own-step records
-			continue;
-		}
-		int64_t r = rlo == rhi ? rlo : read_of_c(off, rlo, rhi, g);
-		for (int e = 0; e < n[it]; ++e) {
-			const int64_t ge = g + e;
-			const unsigned int fl = (w[it] >> (8 * e)) & 0xffu;
-			while (ge >= off[r + 1]) ++r;                          // reads only move forward inside the lane's 4 anchors
-			const int64_t rs = off[r];
-			if (fl & 1) id[rs + p[ge]] = (int32_t)pos;
-			if (fl & 2) id[ge] = (int32_t)(pos + (fl & 1));
-			if (ge == rs) for (int64_t q = r; q >= 0 && off[q] == rs; --q) seeds_off[q] = (int64_t)pos;
-			pos += (fl & 1) + ((fl >> 1) & 1);
-		}
 	}
 }
 
@@ -264,17 +228,23 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_positions(int64_t n_reads, int64_
 // a predecessor (or of its first child) in an earlier block, the offset of a read that started in an earlier block -- is
 // recomputed from block_base[] and the flag bytes in front of it (a short loop, needed by about one anchor in a hundred).
 __device__ __forceinline__ uint32_t pos_before(const uint8_t *__restrict__ flags, const unsigned long long *__restrict__ block_base,
-                                               const uint16_t *__restrict__ sub, int64_t x)
+                                               const uint32_t *__restrict__ sub, int64_t x)
 {
 	const int64_t bx = x / CMP_PER_BLOCK, b0 = bx * CMP_PER_BLOCK;
 	const int l16 = (int)((x - b0) >> 4);                            // k_count's lane: 16 anchors each
-	uint32_t c = (uint32_t)block_base[bx] + sub[bx * 64 + l16];
+	const uint32_t sl = sub[bx * 64 + l16];
 	const int64_t s0 = b0 + 16 * l16;
+	uint32_t c = (uint32_t)block_base[bx] + (sl & 0xffffu) + (uint32_t)__builtin_popcount((sl >> 16) & ((1u << (int)(x - s0)) - 1u));   // late records
 	const uint32_t *w = (const uint32_t*)(flags + s0);               // the array is 16-byte aligned and padded
 	const int nfull = (int)((x - s0) >> 2), tail = (int)((x - s0) & 3);
-	for (int k = 0; k < nfull; ++k) c += (uint32_t)__builtin_popcount(w[k] & 0x03030303u);
-	if (tail) c += (uint32_t)__builtin_popcount(w[nfull] & 0x03030303u & ((1u << (8 * tail)) - 1u));
+	for (int k = 0; k < nfull; ++k) c += (uint32_t)__builtin_popcount(w[k] & 0x02020202u);                    // own-step records
+	if (tail) c += (uint32_t)__builtin_popcount(w[nfull] & 0x02020202u & ((1u << (8 * tail)) - 1u));
 	return c;
+}
+// flags[x] with its late bit (k_count keeps those in sub[])
+__device__ __forceinline__ uint32_t flag_with_late(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ sub, int64_t x)
+{
+	return ((uint32_t)flags[x] & ~1u) | ((sub[x >> 4] >> (16 + (int)(x & 15))) & 1u);     // (a block is 64 runs of 16: sub[] is indexed by x / 16)
 }
 
 __global__ __launch_bounds__(CMP_BLOCK) void k_emit_seeds(Params par, int64_t n_reads, int64_t total,
@@ -284,7 +254,7 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_emit_seeds(Params par, int64_t n_
                                                           const int32_t *__restrict__ first_child,
                                                           const unsigned long long *__restrict__ block_base,
                                                           int64_t *__restrict__ seeds_off, SeedRec *__restrict__ seeds,
-                                                          const int2 *__restrict__ block_reads, const uint16_t *__restrict__ sub)
+                                                          const int2 *__restrict__ block_reads, const uint32_t *__restrict__ sub)
 {
 	__shared__ uint32_t s_pos[CMP_PER_BLOCK];                        // position of the first record an anchor emits (were it to emit any)
 	__shared__ uint8_t s_fl[CMP_PER_BLOCK];
@@ -300,7 +270,8 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_emit_seeds(Params par, int64_t n_
 	uint32_t w = 0;
 	int n = 0;
 	if (g < g1) {
-		w = *(const uint32_t*)(flags + g);
+		const uint32_t l4 = (sub[g >> 4] >> (16 + (int)(g & 15))) & 0xfu;           // the late bits of the four (k_count)
+		w = (*(const uint32_t*)(flags + g) & ~0x01010101u) | (l4 & 1u) | (l4 & 2u) << 7 | (l4 & 4u) << 14 | (l4 & 8u) << 21;
 		n = g1 - g < 4 ? (int)(g1 - g) : 4;
 		if (n < 4) w &= (1u << (8 * n)) - 1u;
 	}
@@ -323,7 +294,7 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_emit_seeds(Params par, int64_t n_
 	__syncthreads();
 	// position of the first record of anchor x (batch-global index; x <= the block's last anchor)
 	auto pos_of = [&](int64_t x) -> uint32_t { return x >= g0 ? s_pos[x - g0] : pos_before(flags, block_base, sub, x); };
-	auto flag_of = [&](int64_t x) -> uint32_t { return x >= g0 ? (uint32_t)s_fl[x - g0] : (uint32_t)flags[x]; };
+	auto flag_of = [&](int64_t x) -> uint32_t { return x >= g0 ? (uint32_t)s_fl[x - g0] : flag_with_late(flags, sub, x); };
 	// records: a thread per anchor, consecutive lanes on consecutive anchors (their records are consecutive too: the stores of a
 	// wave are contiguous)
 	for (int64_t ge = g0 + threadIdx.x; ge < g1; ge += CMP_BLOCK) {
@@ -370,46 +341,6 @@ __global__ void k_finish_offsets(int64_t n_reads, int64_t total, const int64_t *
 	for (int64_t r = n_reads - 1; r >= 0 && off[r] == total; --r) seeds_off[r] = m;
 }
 
-// C4: records
-__global__ __launch_bounds__(CMP_BLOCK) void k_write_seeds(Params par, int64_t n_reads, int64_t total,
-                                                           const int64_t *__restrict__ off, const ulonglong2 *__restrict__ a,
-                                                           const int32_t *__restrict__ f, const int32_t *__restrict__ p,
-                                                           const int32_t *__restrict__ v, const uint8_t *__restrict__ flags,
-                                                           const int32_t *__restrict__ id, const int64_t *__restrict__ seeds_off,
-                                                           SeedRec *__restrict__ seeds, const int2 *__restrict__ block_reads)
-{
-	const int64_t g0 = (int64_t)blockIdx.x * CMP_PER_BLOCK;
-	const int64_t g1 = g0 + CMP_PER_BLOCK < total ? g0 + CMP_PER_BLOCK : total;
-	int64_t rlo, rhi;
-	block_read_range(block_reads, rlo, rhi);
-	const int min_sc = par.min_sc;
-	for (int64_t g = g0 + threadIdx.x; g < g1; g += CMP_BLOCK) {
-		const int fl = flags[g];
-		if (!(fl & 2)) continue;                                                             // not emitted at its own step
-		const int64_t r = rlo == rhi ? rlo : read_of_c(off, rlo, rhi, g);
-		const int64_t rs = off[r];
-		const int32_t so = (int32_t)seeds_off[r];
-		const int32_t q = p[g], fk = f[g], idk = id[g];
-		int32_t pfield = (int32_t)(0xfffffffcu);                                             // (-1)<<2
-		if (q >= 0) {
-			if (fl & 1) {                                                                    // late emission of q, chain.c:292-302
-				const int32_t vq = v[rs + q], fq = f[rs + q];
-				const ulonglong2 aq = a[rs + q];
-				SeedRec rec;
-				rec.x = aq.x; rec.y = aq.y; rec.f = fq;
-				rec.p = (int32_t)(0xfffffffcu | (uint32_t)(vq >= min_sc) | ((uint32_t)(fq < vq) << 1));
-				seeds[idk - 1] = rec;
-			}
-			pfield = (int32_t)((uint32_t)(id[rs + q] - so) << 2);                            // chain.c:310, read-relative index
-		}
-		const ulonglong2 ak = a[g];
-		SeedRec rec;
-		rec.x = ak.x; rec.y = ak.y; rec.f = fk;
-		rec.p = pfield | ((fl >> 3) & 3);                                                    // chain.c:313-314: (v >= min_sc) | (f < v) << 1, from the DP kernel
-		seeds[idk] = rec;
-	}
-}
-
 size_t compact_scratch_bytes(int64_t max_anchors, size_t *flags_bytes, size_t *blocks_bytes)
 {
 	const size_t blocks = (size_t)(max_anchors + CMP_PER_BLOCK - 1) / CMP_PER_BLOCK;
@@ -420,26 +351,17 @@ size_t compact_scratch_bytes(int64_t max_anchors, size_t *flags_bytes, size_t *b
 
 hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off,
                           const void *d_a, const int32_t *d_f, const int32_t *d_p, const int32_t *d_v,
-                          int32_t *d_first_child, int32_t *d_id, int64_t *d_seeds_off, void *d_seeds, CompactScratch sc)
+                          int32_t *d_first_child, int64_t *d_seeds_off, void *d_seeds, CompactScratch sc)
 {
 	hipError_t e;
 	if (n_reads <= 0) return hipMemsetAsync(d_seeds_off, 0, sizeof(int64_t), st);
 	if (total <= 0) return hipMemsetAsync(d_seeds_off, 0, (size_t)(n_reads + 1) * sizeof(int64_t), st);
 	const int64_t blocks = (total + CMP_PER_BLOCK - 1) / CMP_PER_BLOCK;
 	const dim3 g((unsigned)blocks), b(CMP_BLOCK);
-	const dim3 gw((unsigned)((blocks + CMP_BLOCK / 64 - 1) / (CMP_BLOCK / 64)));    // one wave per 1024-anchor block (k_positions)
 	const int64_t cw = (blocks + CNT_BLOCKS_PER_WAVE - 1) / CNT_BLOCKS_PER_WAVE;    // waves of k_count
 	const dim3 gc((unsigned)((cw + CMP_BLOCK / 64 - 1) / (CMP_BLOCK / 64)));
 	hipLaunchKernelGGL(k_count, gc, b, 0, st, n_reads, total, d_off, d_p, d_first_child, sc.flags, sc.block_cnt, sc.block_reads, sc.sub);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, sc.n_seeds)) != hipSuccess) return e;
-	static const bool two_pass = getenv("CHAINDP_COMPACT_TWO_PASS") != nullptr;   // (read once: not on the launch path)
-	if (two_pass) {                          // the earlier form (positions to id[], then records), kept for A/B runs
-		hipLaunchKernelGGL(k_positions, gw, b, 0, st, n_reads, total, d_off, d_p, sc.flags, sc.block_cnt, d_id, d_seeds_off, sc.block_reads);
-		hipLaunchKernelGGL(k_finish_offsets, dim3(1), dim3(1), 0, st, n_reads, total, d_off, sc.n_seeds, d_seeds_off);
-		hipLaunchKernelGGL(k_write_seeds, g, b, 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a, d_f, d_p, d_v, sc.flags, d_id,
-		                   d_seeds_off, (SeedRec*)d_seeds, sc.block_reads);
-		return hipGetLastError();
-	}
 	hipLaunchKernelGGL(k_emit_seeds, g, b, 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a, d_f, d_p, d_v, sc.flags, d_first_child,
 	                   sc.block_cnt, d_seeds_off, (SeedRec*)d_seeds, sc.block_reads, sc.sub);
 	hipLaunchKernelGGL(k_finish_offsets, dim3(1), dim3(1), 0, st, n_reads, total, d_off, sc.n_seeds, d_seeds_off);

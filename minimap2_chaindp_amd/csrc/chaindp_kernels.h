@@ -109,18 +109,19 @@ hipError_t launch_scan_u64(hipStream_t st, int64_t n, unsigned long long *d_data
 
 // compaction into new_seed[] (reference chain.c:286-317): see chaindp_compact.hip
 struct CompactScratch {
-	uint8_t *flags;                  // per anchor: bit0 late; written by the prepass / DP kernel: bit1 "emitted at its own step", bit2 "may be a
-	                                 // first child", bits 3-4 the record flag bits (v >= min_sc, f < v)
+	uint8_t *flags;                  // per anchor, written by the prepass / DP kernel: bit1 "emitted at its own step", bit2 "may be a first
+	                                 // child", bits 3-4 the record flag bits (v >= min_sc, f < v).  (bit0 "late" lives in sub[].)
 	unsigned long long *block_cnt;   // per 1024-anchor block record count; scanned in place
 	unsigned long long *tile_tmp;
 	unsigned long long *n_seeds;     // total records of the batch
 	const int2 *block_reads;         // PrepassScratch::block_reads of the same batch
-	uint16_t *sub;                   // per 1024-anchor block: records in front of each of its 64 runs of 16 anchors (k_count)
+	uint32_t *sub;                   // per run of 16 anchors (64 per 1024-anchor block; k_count): low half = records of the block in front
+	                                 // of the run, high half = the late bits of its 16 anchors
 };
 size_t compact_scratch_bytes(int64_t max_anchors, size_t *flags_bytes, size_t *blocks_bytes);
 hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off,
                           const void *d_a, const int32_t *d_f, const int32_t *d_p, const int32_t *d_v,
-                          int32_t *d_first_child, int32_t *d_id, int64_t *d_seeds_off, void *d_seeds,
+                          int32_t *d_first_child, int64_t *d_seeds_off, void *d_seeds,
                           CompactScratch sc);
 
 // mm_chain_dp_bottom (reference chain.c:329-431) on the GPU: chaindp_bottom.hip.  m = records of the batch.

@@ -48,6 +48,139 @@ __global__ __launch_bounds__(256) void k_block_reads(int64_t n_reads, int64_t to
 	block_reads[b] = make_int2((int)rlo, (int)read_of(off, rlo, n_reads - 1, g1 - 1));
 }
 
+// One wave per 1024-anchor block, sixteen tiles of 64 consecutive anchors in order: the wave streams 16 KB from one place, with
+// PW_DEPTH tiles requested ahead of the one in hand (a workgroup of 256 threads taking one anchor per thread and pass had a single
+// short burst in flight per wave, then its dependent loads of the read's bounds, a block-wide reduction and the end of the
+// workgroup: 3.3 TB/s with neither the vector nor the scalar pipe busy).  What a tile needs from its neighbours comes out of
+// registers -- the last x of the tile before, the first x of the tile after, already loaded -- and the read's bounds, the counts
+// and the q_span sum are wave-uniform state carried from tile to tile: no LDS, no barrier, one 128-byte store of the block's
+// sixteen start masks, one atomic per block and read.
+#define PW_TILES (PRE_PER_BLOCK / 64)
+#define PW_DEPTH 4                                                   // tiles requested ahead of the one in hand
+
+template <bool FULL>                                                 // FULL: all 1024 anchors exist (every block but the batch's last)
+__device__ __forceinline__ void prepass_block(const Params &par, const int64_t b, const int lane, const int64_t total,
+                                              const int64_t *__restrict__ off, const ulonglong2 *__restrict__ a,
+                                              unsigned long long *__restrict__ sumq, uint64_t *__restrict__ start_mask,
+                                              unsigned long long *__restrict__ block_cnt,
+                                              int32_t *__restrict__ f, int32_t *__restrict__ p, int32_t *__restrict__ v,
+                                              uint8_t *__restrict__ flags, const int2 *__restrict__ block_reads)
+{
+	const uint64_t maxx = (uint64_t)(int64_t)par.max_dist_x;
+	const int64_t g0 = b * PRE_PER_BLOCK;
+	const int64_t g1 = FULL ? g0 + PRE_PER_BLOCK : total;
+	const int n_in = FULL ? PRE_PER_BLOCK : (int)(g1 - g0);          // anchors of the block
+	const int nt = (n_in + 63) >> 6;                                 // tiles of the block
+	const ulonglong2 *const ab = a + g0 + lane;
+	ulonglong2 an_[PW_DEPTH];
+#pragma unroll
+	for (int k = 0; k < PW_DEPTH; ++k) {
+		an_[k] = make_ulonglong2(0, 0);                              // (an anchor that does not exist: x = 0, q_span = 0, no segment id)
+		if (FULL || k * 64 + lane < n_in) an_[k] = ab[k * 64];
+	}
+	const int2 rr = block_reads[b];                                  // reads of the block's first and last anchor (k_block_reads)
+	uint64_t x_carry = g0 > 0 ? a[g0 - 1].x : 0;                     // x of the anchor before the tile in hand (wave-uniform)
+	const uint64_t x_after = g1 < total ? a[g1].x : 0;               // x of the anchor after the block
+	// the read the tile in hand starts in, its bounds relative to the block (32-bit: the scalar unit compares no 64-bit order):
+	// rs_b < 0 when it starts before the block, re_b capped when it ends far behind it
+	int64_t r_cur = rr.x;
+	auto bounds = [&](int &rs_b, int &re_b) {
+		const int64_t ds = off[r_cur] - g0, de = off[r_cur + 1] - g0;
+		rs_b = ds < 0 ? -1 : (int)ds;
+		re_b = ((uint64_t)de >> 20) ? 1 << 20 : (int)de;
+	};
+	int rs_b, re_b;
+	bounds(rs_b, re_b);
+	unsigned int w_sum = 0, any_seg = 0;                             // per lane, of r_cur
+	uint64_t span0_m = 0;                                            // lanes that saw a zero q_span in r_cur
+	unsigned int n_units = 0, n_singles = 0;                         // wave-uniform
+	uint32_t mk_lo = 0, mk_hi = 0;                                   // lane t: the start mask of tile t
+	int32_t *fb = f + g0 + lane, *pb = p + g0 + lane, *vb = v + g0 + lane;
+	uint8_t *flb = flags + g0 + lane;
+	auto flush = [&]() {                                             // r_cur's share of the block is complete
+		unsigned int s = w_sum;
+		for (int d = 32; d; d >>= 1) s += __shfl_xor(s, d, 64);
+		if (lane == 0 && s) atomicAdd(&sumq[r_cur], (unsigned long long)s);
+		if (__builtin_amdgcn_ballot_w64(any_seg != 0) && lane == 0) atomicOr(&sumq[r_cur], SUMQ_SEG_FLAG);     // rare: multi-segment reads only
+		if (span0_m && lane == 0) atomicOr(&sumq[r_cur], SUMQ_SPAN0_FLAG);                                      // (never, in minimap2's own anchors)
+		w_sum = 0; any_seg = 0; span0_m = 0;
+	};
+#pragma unroll 1
+	for (int t0 = 0; t0 < PW_TILES; t0 += PW_DEPTH) {
+#pragma unroll
+		for (int j = 0; j < PW_DEPTH; ++j) {
+			const int t = t0 + j, tb = t * 64;                           // the tile and its place in the block
+			if (!FULL && t >= nt) break;
+			const int in_tile = FULL ? 64 : (n_in - tb < 64 ? n_in - tb : 64);
+			const uint64_t have_m = FULL || in_tile == 64 ? ~0ull : (1ull << in_tile) - 1;
+			const ulonglong2 an = an_[j];
+			uint64_t x_follow = x_after;
+			if (t + 1 < (FULL ? PW_TILES : nt)) x_follow = readlane_u64(an_[(j + 1) % PW_DEPTH].x, 0);
+			const uint32_t xlo = (uint32_t)an.x, xhi = (uint32_t)(an.x >> 32);
+			const uint32_t plo = (uint32_t)dpp_or_old<DPP_WAVE_SHR1, 0xf>((int)(uint32_t)x_carry, (int)xlo);          // lane 0 keeps the carry
+			const uint32_t phi = (uint32_t)dpp_or_old<DPP_WAVE_SHR1, 0xf>((int)(uint32_t)(x_carry >> 32), (int)xhi);
+			const uint32_t nlo = (uint32_t)dpp_or_old<DPP_WAVE_SHL1, 0xf>((int)(uint32_t)x_follow, (int)xlo);         // lane 63 keeps what follows
+			const uint32_t nhi = (uint32_t)dpp_or_old<DPP_WAVE_SHL1, 0xf>((int)(uint32_t)(x_follow >> 32), (int)xhi);
+			const uint64_t xprev = (uint64_t)phi << 32 | plo, xnext = (uint64_t)nhi << 32 | nlo;
+			const uint32_t yhi = (uint32_t)(an.y >> 32);
+			const int span = (int)(yhi & 0xffu);
+			if (tb >= re_b) {                                            // the tile starts in a later read
+				flush();
+				r_cur = read_of(off, r_cur, rr.y, g0 + tb);
+				bounds(rs_b, re_b);
+			}
+			uint64_t start_m, single_m;
+			if (tb + in_tile <= re_b) {                                  // the whole tile lies in r_cur: the usual tile.  Lane masks, combined by the scalar unit
+				const uint64_t far_prev = __builtin_amdgcn_uicmpl(an.x - xprev, maxx, 34), far_next = __builtin_amdgcn_uicmpl(xnext - an.x, maxx, 34);
+				const int l_re = re_b - tb;                                // the read ends before lane l_re of this tile (>= in_tile)
+				const uint64_t last_m = l_re <= 64 ? 1ull << (l_re - 1) : 0ull;
+				start_m = (far_prev | (rs_b == tb ? 1ull : 0ull)) & have_m;
+				single_m = start_m & (far_next | last_m);
+				span0_m |= __builtin_amdgcn_uicmp((unsigned)span, 0u, 32) & have_m;
+				any_seg |= yhi & 0x00ff0000u;
+				w_sum += (unsigned int)span;
+			} else {                                                     // a read ends inside the tile: every lane finds its own read
+				bool start = false, single = false;
+				if (FULL || lane < in_tile) {
+					const int64_t g = g0 + tb + lane;
+					const int64_t r = read_of(off, r_cur, rr.y, g);
+					const int64_t rs_l = off[r], re_l = off[r + 1];
+					start = g == rs_l || an.x - xprev > maxx;
+					single = start && (g + 1 >= re_l || xnext - an.x > maxx);
+					if (r == r_cur) {
+						any_seg |= yhi & 0x00ff0000u;
+						w_sum += (unsigned int)span;
+					} else {
+						if (yhi & 0x00ff0000u) atomicOr(&sumq[r], SUMQ_SEG_FLAG);
+						if (span) atomicAdd(&sumq[r], (unsigned long long)span);
+					}
+					if (span == 0) atomicOr(&sumq[r], SUMQ_SPAN0_FLAG);
+				}
+				start_m = __builtin_amdgcn_ballot_w64(start);
+				single_m = __builtin_amdgcn_ballot_w64(single);
+			}
+			if (__builtin_amdgcn_inverse_ballot_w64(single_m)) {         // chain.c:251,283-284 with an empty window
+				fb[j * 64] = span; pb[j * 64] = -1; vb[j * 64] = span;
+				flb[j * 64] = (uint8_t)(span >= par.min_sc ? 2 | 8 : 0);    // emitted at its own step iff v >= min_sc (chain.c:304); bit3 = v >= min_sc
+			}
+			const uint64_t em = start_m & ~single_m;
+			n_units += (unsigned int)__builtin_popcountll(em);
+			n_singles += (unsigned int)__builtin_popcountll(single_m);
+			asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"           // (one SGPR and M0 per instruction: the constant bus)
+			    : "+v"(mk_lo), "+v"(mk_hi) : "s"((uint32_t)em), "s"(t), "s"((uint32_t)(em >> 32)) : "m0");
+			x_carry = readlane_u64(an.x, 63);                            // (a tile that is not full is the last one)
+			if (t0 + PW_DEPTH < PW_TILES) {                              // its slot takes the tile PW_DEPTH further on
+				an_[j] = make_ulonglong2(0, 0);
+				if (FULL || tb + PW_DEPTH * 64 + lane < n_in) an_[j] = ab[tb + PW_DEPTH * 64];
+			}
+		}
+		fb += PW_DEPTH * 64; pb += PW_DEPTH * 64; vb += PW_DEPTH * 64; flb += PW_DEPTH * 64;
+	}
+	flush();
+	if (lane < nt) start_mask[(g0 >> 6) + lane] = (uint64_t)mk_hi << 32 | mk_lo;
+	if (lane == 0) block_cnt[b] = (unsigned long long)n_singles << 32 | n_units;   // two counters, one scan
+}
+
 __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_reads, int64_t total,
                                                        const int64_t *__restrict__ off, const ulonglong2 *__restrict__ a,
                                                        unsigned long long *__restrict__ sumq, uint64_t *__restrict__ start_mask,
@@ -56,128 +189,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_rea
                                                        uint8_t *__restrict__ flags,
                                                        const int2 *__restrict__ block_reads)
 {
-	__shared__ unsigned int s_sum, s_units, s_singles;
 	const int lane = threadIdx.x & 63;
-	const uint64_t maxx = (uint64_t)(int64_t)par.max_dist_x;
-	const int64_t g0 = (int64_t)blockIdx.x * PRE_PER_BLOCK;
-	const int64_t g1 = g0 + PRE_PER_BLOCK < total ? g0 + PRE_PER_BLOCK : total;
-	if (threadIdx.x == 0) { s_sum = 0; s_units = 0; s_singles = 0; }
-	__syncthreads();
-	const int2 rr = block_reads[blockIdx.x];                       // reads of the block's first and last anchor (k_block_reads)
-	const int64_t rlo = rr.x, rhi = rr.y;
-	const bool one_read = rlo == rhi;
-	unsigned int w_sum = 0, w_units = 0, w_singles = 0;
-	// all loads of the block's four passes are issued before the first is used (one anchor per thread and pass would
-	// leave a single 16-byte load in flight per thread); neighbours come from the adjacent lanes, and from memory
-	// only at the two ends of a wave's 64 anchors
-	constexpr int PASSES = PRE_PER_BLOCK / PRE_BLOCK;
-	ulonglong2 an_[PASSES];
-	uint64_t xb_[PASSES], xe_[PASSES];
-#pragma unroll
-	for (int k = 0; k < PASSES; ++k) {
-		const int64_t g = g0 + (int64_t)k * PRE_BLOCK + threadIdx.x;
-		an_[k] = make_ulonglong2(0, 0); xb_[k] = 0; xe_[k] = 0;
-		if (g < g1) an_[k] = a[g];
-		if (g < g1 && lane == 0 && g > 0) xb_[k] = a[g - 1].x;
-		if (g < g1 && (lane == 63 || g + 1 == g1) && g + 1 < total) xe_[k] = a[g + 1].x;
-	}
-	if (one_read) {
-		// ---- the usual block: inside one read.  Same arithmetic as the general loop below with what is block-uniform hoisted (the
-		// read's bounds), neighbours by DPP shifts instead of LDS permutes, the rare per-anchor events (a segment id, a zero q_span)
-		// found by ballots, and the singleton stores through block-relative pointers: about half the instructions per anchor --
-		// the kernel was issue-bound, not bandwidth-bound (80 vector + 60 scalar instructions per 64 anchors at 3 TB/s).
-		const int64_t rs = off[rlo], re = off[rlo + 1];
-		int32_t *const fb = f + g0, *const pb = p + g0, *const vb = v + g0;
-		uint8_t *const flb = flags + g0;
-		unsigned int any_seg = 0, any_span0 = 0;
-#pragma unroll
-		for (int k = 0; k < PASSES; ++k) {
-			const int64_t gb = g0 + (int64_t)k * PRE_BLOCK;
-			if (gb >= g1) break;
-			const int t = k * PRE_BLOCK + (int)threadIdx.x;              // the anchor's place in the block
-			const int64_t g = g0 + t;
-			const bool have = g < g1;
-			const ulonglong2 an = an_[k];
-			const uint32_t xlo = (uint32_t)an.x, xhi = (uint32_t)(an.x >> 32);
-			uint32_t plo = (uint32_t)wave_shift_up1((int)xlo, 0), phi = (uint32_t)wave_shift_up1((int)xhi, 0);
-			uint32_t nlo = (uint32_t)dpp_or_old<DPP_WAVE_SHL1, 0xf>(0, (int)xlo), nhi = (uint32_t)dpp_or_old<DPP_WAVE_SHL1, 0xf>(0, (int)xhi);
-			if (lane == 0) { plo = (uint32_t)xb_[k]; phi = (uint32_t)(xb_[k] >> 32); }
-			if (lane == 63 || g + 1 == g1) { nlo = (uint32_t)xe_[k]; nhi = (uint32_t)(xe_[k] >> 32); }
-			const uint64_t xprev = (uint64_t)phi << 32 | plo, xnext = (uint64_t)nhi << 32 | nlo;
-			const uint32_t yhi = (uint32_t)(an.y >> 32);
-			const int span = have ? (int)(yhi & 0xffu) : 0;
-			const bool start = have && (g == rs || an.x - xprev > maxx);
-			const bool single = start && (g + 1 >= re || xnext - an.x > maxx);
-			any_seg |= have ? (yhi & 0x00ff0000u) : 0u;
-			any_span0 |= (have && span == 0) ? 1u : 0u;
-			if (single) {                                              // chain.c:251,283-284 with an empty window
-				fb[t] = span; pb[t] = -1; vb[t] = span;
-				flb[t] = (uint8_t)(span >= par.min_sc ? 2 | 8 : 0);       // emitted at its own step iff v >= min_sc (chain.c:304); bit3 = v >= min_sc
-			}
-			w_sum += (unsigned int)span;
-			const uint64_t em = __builtin_amdgcn_ballot_w64(start && !single);
-			const uint64_t sm = __builtin_amdgcn_ballot_w64(single);
-			if (lane == 0 && gb + (threadIdx.x & ~63) < g1) start_mask[(gb + (threadIdx.x & ~63)) >> 6] = em;
-			w_units += (unsigned int)__builtin_popcountll(em);
-			w_singles += (unsigned int)__builtin_popcountll(sm);
-		}
-		if (__builtin_amdgcn_ballot_w64(any_seg != 0) && lane == 0) atomicOr(&sumq[rlo], SUMQ_SEG_FLAG);      // rare: multi-segment reads only
-		if (__builtin_amdgcn_ballot_w64(any_span0 != 0) && lane == 0) atomicOr(&sumq[rlo], SUMQ_SPAN0_FLAG);  // (never, in minimap2's own anchors)
-	} else
-#pragma unroll
-	for (int k = 0; k < PASSES; ++k) {
-		const int64_t gb = g0 + (int64_t)k * PRE_BLOCK;
-		if (gb >= g1) break;
-		const int64_t g = gb + threadIdx.x;
-		const bool have = g < g1;
-		const ulonglong2 an = an_[k];
-		uint64_t xprev = (uint64_t)__shfl_up((unsigned long long)an.x, 1, 64), xnext = (uint64_t)__shfl_down((unsigned long long)an.x, 1, 64);
-		if (lane == 0) xprev = xb_[k];
-		if (lane == 63 || g + 1 == g1) xnext = xe_[k];
-		bool start = false, single = false;
-		int span = 0;
-		int64_t r = rlo;
-		if (have) {
-			if (!one_read) r = read_of(off, rlo, rhi, g);
-			const int64_t rs = off[r], re = off[r + 1];
-			span = span_of_hi((uint32_t)(an.y >> 32));
-			if (seg_of_hi((uint32_t)(an.y >> 32)) != 0) atomicOr(&sumq[r], SUMQ_SEG_FLAG);   // rare: multi-segment reads only
-			if (span == 0) atomicOr(&sumq[r], SUMQ_SPAN0_FLAG);                                // (never, in minimap2's own anchors: q_span is the k-mer span)
-			start = g == rs || an.x - xprev > maxx;
-			const bool next_starts = g + 1 >= re || xnext - an.x > maxx;
-			single = start && next_starts;
-			if (single) {                                          // chain.c:251,283-284 with an empty window
-				f[g] = span; p[g] = -1; v[g] = span;
-				flags[g] = (uint8_t)(span >= par.min_sc ? 2 | 8 : 0);  // emitted at its own step iff v >= min_sc (chain.c:304); bit3 = v >= min_sc
-			}
-		}
-		// q_span sum (chain.c:240): per block when the block sits inside one read, else per wave when the
-		// wave does, else (the one wave that straddles a read boundary) per lane
-		if (one_read) w_sum += (unsigned int)span;
-		else {
-			const int64_t r_first = (int64_t)readlane_u64((uint64_t)r, 0);
-			if (__builtin_amdgcn_ballot_w64(have && r != r_first) == 0) {
-				int sw = have ? span : 0;
-				for (int d = 32; d; d >>= 1) sw += __shfl_xor(sw, d, 64);
-				if (lane == 0 && sw) atomicAdd(&sumq[r_first], (unsigned long long)sw);
-			} else if (have) atomicAdd(&sumq[r], (unsigned long long)span);
-		}
-		const uint64_t em = __builtin_amdgcn_ballot_w64(start && !single);
-		const uint64_t sm = __builtin_amdgcn_ballot_w64(single);
-		if (lane == 0 && gb + (threadIdx.x & ~63) < g1) start_mask[(gb + (threadIdx.x & ~63)) >> 6] = em;
-		w_units += (unsigned int)__builtin_popcountll(em);
-		w_singles += (unsigned int)__builtin_popcountll(sm);
-	}
-	if (one_read) {
-		for (int d = 32; d; d >>= 1) w_sum += __shfl_xor(w_sum, d, 64);
-		if (lane == 0 && w_sum) atomicAdd(&s_sum, w_sum);
-	}
-	if (lane == 0) { atomicAdd(&s_units, w_units); atomicAdd(&s_singles, w_singles); }
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		if (one_read && s_sum) atomicAdd(&sumq[rlo], (unsigned long long)s_sum);
-		block_cnt[blockIdx.x] = (unsigned long long)s_singles << 32 | s_units;   // two counters, one scan
-	}
+	const int64_t b = (int64_t)blockIdx.x * (PRE_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int64_t g0 = b * PRE_PER_BLOCK;
+	if (g0 >= total) return;
+	if (g0 + PRE_PER_BLOCK <= total) prepass_block<true>(par, b, lane, total, off, a, sumq, start_mask, block_cnt, f, p, v, flags, block_reads);
+	else prepass_block<false>(par, b, lane, total, off, a, sumq, start_mask, block_cnt, f, p, v, flags, block_reads);
 }
 
 // Units are scheduled longest first (a unit is one wave's serial work, so a long one started last would be the
@@ -198,8 +215,11 @@ __global__ __launch_bounds__(256) void k_emit_units(int64_t n_reads, int64_t n_w
 	__shared__ unsigned int s_hist[UNIT_CLASSES];
 	if (threadIdx.x < UNIT_CLASSES) s_hist[threadIdx.x] = 0;
 	__syncthreads();
-	const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	uint64_t m = w < n_words ? start_mask[w] : 0;
+	// a workgroup takes many 256-word pieces and adds its class counts to the batch's once at the end: with a workgroup per piece
+	// the adds to the few classes that hold most units queued up at their addresses (37 000 workgroups on the 100k-read job,
+	// ~7.5 ns per same-address atomic: 0.3 of the kernel's 0.44 ms)
+	for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * blockDim.x) {
+	uint64_t m = start_mask[w];
 	if (m) {
 		const int64_t b = w / PRE_WORDS;
 		uint64_t pos = (uint32_t)block_base[b];             // low word: units before this block
@@ -208,12 +228,12 @@ __global__ __launch_bounds__(256) void k_emit_units(int64_t n_reads, int64_t n_w
 		// (fourteen dependent loads for 12 500 reads; a block usually lies in one read or straddles two)
 		const int2 rr = block_reads[b];
 		int64_t r = read_of(off, rr.x, rr.y, w << 6);
+		int64_t re = off[r + 1];                            // (kept across the word's units: a load per unit was a trip to L2 per unit, one after the other)
 		while (m) {
 			const int bit = __builtin_ctzll(m);
 			m &= m - 1;
 			const int64_t g = (w << 6) + bit;
-			while (g >= off[r + 1]) ++r;                    // units of one word are in anchor order; reads only move forward
-			const int64_t re = off[r + 1];
+			while (g >= re) re = off[++r + 1];              // units of one word are in anchor order; reads only move forward
 			// upper bound of the unit: the next unit's start or the end of the read (singletons in between are
 			// not units, so this can overshoot the true end; the DP kernel finds the true end itself)
 			int64_t next = -1;
@@ -228,6 +248,7 @@ __global__ __launch_bounds__(256) void k_emit_units(int64_t n_reads, int64_t n_w
 			units[pos++] = u;
 			atomicAdd(&s_hist[unit_class(u.len)], 1u);
 		}
+	}
 	}
 	__syncthreads();
 	if (threadIdx.x < UNIT_CLASSES && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
@@ -338,11 +359,11 @@ hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, in
 	const int64_t blocks = (total + PRE_PER_BLOCK - 1) / PRE_PER_BLOCK;
 	const int64_t words = (total + 63) / 64;
 	hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, st, n_reads, total, d_off, sc.block_reads);
-	hipLaunchKernelGGL(k_prepass, dim3((unsigned)blocks), dim3(PRE_BLOCK), 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a,
+	hipLaunchKernelGGL(k_prepass, dim3((unsigned)((blocks + PRE_BLOCK / 64 - 1) / (PRE_BLOCK / 64))), dim3(PRE_BLOCK), 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a,
 	                   d_sumq, sc.start_mask, sc.block_cnt, d_f, d_p, d_v, d_flags, sc.block_reads);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, d_counters)) != hipSuccess) return e;
 	if ((e = hipMemsetAsync(sc.hist, 0, 2 * UNIT_CLASSES * sizeof(unsigned int), st)) != hipSuccess) return e;
-	hipLaunchKernelGGL(k_emit_units, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, n_reads, words, d_off,
+	hipLaunchKernelGGL(k_emit_units, dim3((unsigned)((words + 255) / 256 < 2048 ? (words + 255) / 256 : 2048)), dim3(256), 0, st, n_reads, words, d_off,
 	                   sc.start_mask, sc.block_cnt, sc.units_tmp, sc.hist, sc.block_reads);
 	hipLaunchKernelGGL(k_unit_bases, dim3(1), dim3(64), 0, st, sc.hist, sc.hist + UNIT_CLASSES, d_unit_aux ? sc.key_range : nullptr);
 	hipLaunchKernelGGL(k_unit_scatter, dim3((unsigned)(blocks < 1024 ? (blocks > 0 ? blocks : 1) : 1024)), dim3(256), 0, st, d_counters, sc.units_tmp,
