@@ -27,6 +27,8 @@ struct chaindp_ctx {
 	// resident batch
 	int64_t n_reads = 0, total = 0, n_seeds = 0;
 	bool has_n_segs = false, ran = false, compact_ready = false;
+	bool singles_pending = false;    // the last run left f, p, v, flags[] of its singletons to k_fill_singles (chaindp_download runs it)
+	chaindp_params_t ran_par{};      // the parameters of that run
 	int64_t *d_off = nullptr;
 	void *d_a = nullptr;
 	int32_t *d_n_segs = nullptr;
@@ -140,7 +142,7 @@ extern "C" void chaindp_destroy(chaindp_ctx_t *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	for (auto &es : ctx->pending) for (int k = 0; k < es.n; ++k) (void)hipEventDestroy(es.e[k]);
 	void *bufs[] = {ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_sumq, ctx->d_units,
-	                ctx->d_counters, ctx->d_unit_aux, ctx->d_left, ctx->d_left_cnt, ctx->d_deep, ctx->pre.start_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->pre.units_tmp, ctx->pre.hist, ctx->pre.block_reads, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->cmp.sub, ctx->d_first_child, ctx->d_seeds_off, ctx->d_seeds};
+	                ctx->d_counters, ctx->d_unit_aux, ctx->d_left, ctx->d_left_cnt, ctx->d_deep, ctx->pre.start_mask, ctx->pre.single_mask, ctx->pre.emit_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->pre.units_tmp, ctx->pre.hist, ctx->pre.block_reads, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->cmp.sub, ctx->d_first_child, ctx->d_seeds_off, ctx->d_seeds};
 	for (void *b : bufs) if (b) (void)hipFree(b);
 	for (void *b : ctx->bot_allocs) if (b) (void)hipFree(b);
 	void *sbufs[] = {ctx->seed.kept, ctx->seed.used, ctx->seed.src, ctx->seed.mstate, ctx->seed.tile_tmp, ctx->seed.totals, ctx->seed.stacks,
@@ -187,6 +189,9 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	size_t mask_bytes = 0, blocks_bytes = 0;
 	chaindp::prepass_scratch_bytes(ctx->cap_anchors, &mask_bytes, &blocks_bytes);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.start_mask, mask_bytes);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.single_mask, mask_bytes);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.emit_mask, mask_bytes);
+	ctx->cmp.single_mask = ctx->pre.single_mask; ctx->cmp.emit_mask = ctx->pre.emit_mask;
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.block_cnt, blocks_bytes);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.tile_tmp, blocks_bytes);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->pre.units_tmp, (na / 2 + 1) * sizeof(Unit));
@@ -249,7 +254,7 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		es.n = 3;
 	}
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[0], st));
-	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, d_f, d_p, d_v, ctx->cmp.flags, ctx->d_unit_aux));
+	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, ctx->d_unit_aux));
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[1], st));
 	// per-read gap-cost table for the fast variant (skipped when the table would not apply)
 	uint16_t *lut = nullptr;
@@ -333,7 +338,7 @@ extern "C" int chaindp_run(chaindp_ctx_t *ctx, const chaindp_params_t *par)
 	if (!ctx) return CHAINDP_ERR_ARG;
 	int rc = run_on_stream(ctx, par, ctx->n_reads, ctx->total, ctx->d_off, ctx->d_a, ctx->has_n_segs ? ctx->d_n_segs : nullptr,
 	                       ctx->d_f, ctx->d_p, ctx->d_v, ctx->stream);
-	if (rc == CHAINDP_OK) ctx->ran = true;
+	if (rc == CHAINDP_OK) { ctx->ran = true; ctx->singles_pending = true; ctx->ran_par = *par; }
 	return rc;
 }
 
@@ -343,8 +348,13 @@ extern "C" int chaindp_run_device(chaindp_ctx_t *ctx, const chaindp_params_t *pa
 {
 	if (!ctx) return CHAINDP_ERR_ARG;
 	if (!d_off || (total_anchors > 0 && (!d_a || !d_f || !d_p || !d_v))) { ctx->err = "NULL device pointer"; return CHAINDP_ERR_ARG; }
-	return run_on_stream(ctx, par, n_reads, total_anchors, (const int64_t*)d_off, d_a, (const int32_t*)d_n_segs,
-	                     (int32_t*)d_f, (int32_t*)d_p, (int32_t*)d_v, stream ? (hipStream_t)stream : ctx->stream);
+	hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+	const int rc = run_on_stream(ctx, par, n_reads, total_anchors, (const int64_t*)d_off, d_a, (const int32_t*)d_n_segs,
+	                             (int32_t*)d_f, (int32_t*)d_p, (int32_t*)d_v, st);
+	if (rc != CHAINDP_OK) return rc;
+	// the caller reads its own arrays: the singletons' entries are written right away
+	HIP_TRY(ctx, chaindp::launch_fill_singles(st, to_params(par), total_anchors, d_a, ctx->pre, (int32_t*)d_f, (int32_t*)d_p, (int32_t*)d_v, ctx->cmp.flags));
+	return CHAINDP_OK;
 }
 
 extern "C" int chaindp_sync(chaindp_ctx_t *ctx)
@@ -361,6 +371,10 @@ extern "C" int chaindp_download(chaindp_ctx_t *ctx, int32_t *f, int32_t *p, int3
 	if (!ctx->ran) { ctx->err = "chaindp_download before chaindp_run"; return CHAINDP_ERR_ARG; }
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const size_t bytes = (size_t)ctx->total * 4;
+	if (ctx->singles_pending) {          // (the compaction works from the prepass' masks: only this call looks at the singletons' f, p, v)
+		HIP_TRY(ctx, chaindp::launch_fill_singles(ctx->stream, to_params(&ctx->ran_par), ctx->total, ctx->d_a, ctx->pre, ctx->d_f, ctx->d_p, ctx->d_v, ctx->cmp.flags));
+		ctx->singles_pending = false;
+	}
 	if (bytes) {
 		if (f) HIP_TRY(ctx, hipMemcpyAsync(f, ctx->d_f, bytes, hipMemcpyDeviceToHost, ctx->stream));
 		if (p) HIP_TRY(ctx, hipMemcpyAsync(p, ctx->d_p, bytes, hipMemcpyDeviceToHost, ctx->stream));

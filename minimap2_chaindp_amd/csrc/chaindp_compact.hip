@@ -117,6 +117,17 @@ hipError_t launch_scan_u64(hipStream_t st, int64_t n, unsigned long long *d_data
 // C2: late bit and per-block record counts.  Only anchors with bit2 look at p[] and first_child[]; for everything
 // else this pass reads one byte per anchor.  One wave per 1024-anchor block, 16 consecutive anchors per lane (one
 // 16-byte load in flight per lane; a 256-thread block per 1024 anchors was bound by its own start-up latency).
+// Flag bytes of four consecutive anchors with the singletons among them set right (s4 / e4: the singleton / emitted-singleton bits
+// of the four, from the prepass' masks -- nobody stores a singleton's flag byte, what the array holds there is an earlier batch's).
+// A singleton: bit5; an emitted one also "own step" (bit1) and v >= min_sc (bit3); never a first-child candidate, never late.
+__device__ __forceinline__ uint32_t flags_with_singles(uint32_t w, uint32_t s4, uint32_t e4)
+{
+	const uint32_t sb = (s4 * 0x00204081u) & 0x01010101u, eb = (e4 * 0x00204081u) & 0x01010101u;   // bit i -> bit 0 of byte i
+	return (w & ~(sb * 0xffu)) | sb * 0x20u | eb * 0x0au;
+}
+// the mask bits of the n <= 16 anchors from g on (g a multiple of 4: they sit in one word)
+__device__ __forceinline__ uint32_t mask_bits16(const uint64_t *__restrict__ m, int64_t g) { return (uint32_t)(m[g >> 6] >> (g & 63)) & 0xffffu; }
+
 __device__ __forceinline__ unsigned int flag_word(const uint4 &v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 
 #define CNT_BLOCKS_PER_WAVE 4          // 1024-anchor blocks a wave of k_count takes: their flag loads are all in flight before the first is used
@@ -129,7 +140,8 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t to
                                                      const int64_t *__restrict__ off, const int32_t *__restrict__ p,
                                                      const int32_t *__restrict__ first_child,
                                                      const uint8_t *__restrict__ flags, unsigned long long *__restrict__ block_cnt,
-                                                     const int2 *__restrict__ block_reads, uint32_t *__restrict__ sub)
+                                                     const int2 *__restrict__ block_reads, uint32_t *__restrict__ sub,
+                                                     const uint64_t *__restrict__ single_mask, const uint64_t *__restrict__ emit_mask)
 {
 	const int lane = threadIdx.x & 63;
 	const int64_t blk0 = ((int64_t)blockIdx.x * (CMP_BLOCK / 64) + (threadIdx.x >> 6)) * CNT_BLOCKS_PER_WAVE;
@@ -141,14 +153,22 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t to
 	// has candidates (two or three times), not sixteen times.
 	uint4 vv[CNT_BLOCKS_PER_WAVE];
 	int2 rr[CNT_BLOCKS_PER_WAVE];
+	uint32_t sm[CNT_BLOCKS_PER_WAVE];                               // the lane's singleton bits (low half) and emitted-singleton bits
 	unsigned long long cand = 0;                                    // bit 16 b + e: anchor e of this lane's 16 in block b may be a first child
 #pragma unroll
 	for (int b = 0; b < CNT_BLOCKS_PER_WAVE; ++b) {
 		const int64_t g = (blk0 + b) * CMP_PER_BLOCK + 16 * lane;
 		const int64_t g1 = (blk0 + b + 1) * CMP_PER_BLOCK < total ? (blk0 + b + 1) * CMP_PER_BLOCK : total;
 		vv[b] = make_uint4(0u, 0u, 0u, 0u);
-		rr[b] = make_int2(0, 0);
-		if (g < g1) { vv[b] = *(const uint4*)(flags + g); rr[b] = block_reads[blk0 + b]; }      // 16 flag bytes (the array is padded to 16 B)
+		rr[b] = make_int2(0, 0); sm[b] = 0;
+		if (g < g1) { vv[b] = *(const uint4*)(flags + g); rr[b] = block_reads[blk0 + b]; sm[b] = mask_bits16(single_mask, g) | mask_bits16(emit_mask, g) << 16; }   // 16 flag bytes (the array is padded to 16 B)
+	}
+#pragma unroll
+	for (int b = 0; b < CNT_BLOCKS_PER_WAVE; ++b) {                 // the singletons' bytes
+		vv[b].x = flags_with_singles(vv[b].x, sm[b] & 0xfu, (sm[b] >> 16) & 0xfu);
+		vv[b].y = flags_with_singles(vv[b].y, (sm[b] >> 4) & 0xfu, (sm[b] >> 20) & 0xfu);
+		vv[b].z = flags_with_singles(vv[b].z, (sm[b] >> 8) & 0xfu, (sm[b] >> 24) & 0xfu);
+		vv[b].w = flags_with_singles(vv[b].w, (sm[b] >> 12) & 0xfu, (sm[b] >> 28) & 0xfu);
 	}
 #pragma unroll
 	for (int b = 0; b < CNT_BLOCKS_PER_WAVE; ++b) {
@@ -228,7 +248,8 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_count(int64_t n_reads, int64_t to
 // a predecessor (or of its first child) in an earlier block, the offset of a read that started in an earlier block -- is
 // recomputed from block_base[] and the flag bytes in front of it (a short loop, needed by about one anchor in a hundred).
 __device__ __forceinline__ uint32_t pos_before(const uint8_t *__restrict__ flags, const unsigned long long *__restrict__ block_base,
-                                               const uint32_t *__restrict__ sub, int64_t x)
+                                               const uint32_t *__restrict__ sub, const uint64_t *__restrict__ single_mask,
+                                               const uint64_t *__restrict__ emit_mask, int64_t x)
 {
 	const int64_t bx = x / CMP_PER_BLOCK, b0 = bx * CMP_PER_BLOCK;
 	const int l16 = (int)((x - b0) >> 4);                            // k_count's lane: 16 anchors each
@@ -236,14 +257,18 @@ __device__ __forceinline__ uint32_t pos_before(const uint8_t *__restrict__ flags
 	const int64_t s0 = b0 + 16 * l16;
 	uint32_t c = (uint32_t)block_base[bx] + (sl & 0xffffu) + (uint32_t)__builtin_popcount((sl >> 16) & ((1u << (int)(x - s0)) - 1u));   // late records
 	const uint32_t *w = (const uint32_t*)(flags + s0);               // the array is 16-byte aligned and padded
+	const uint32_t s16 = mask_bits16(single_mask, s0), e16 = mask_bits16(emit_mask, s0);
 	const int nfull = (int)((x - s0) >> 2), tail = (int)((x - s0) & 3);
-	for (int k = 0; k < nfull; ++k) c += (uint32_t)__builtin_popcount(w[k] & 0x02020202u);                    // own-step records
-	if (tail) c += (uint32_t)__builtin_popcount(w[nfull] & 0x02020202u & ((1u << (8 * tail)) - 1u));
+	for (int k = 0; k < nfull; ++k)                                  // own-step records
+		c += (uint32_t)__builtin_popcount(flags_with_singles(w[k], (s16 >> (4 * k)) & 0xfu, (e16 >> (4 * k)) & 0xfu) & 0x02020202u);
+	if (tail) c += (uint32_t)__builtin_popcount(flags_with_singles(w[nfull], (s16 >> (4 * nfull)) & 0xfu, (e16 >> (4 * nfull)) & 0xfu) & 0x02020202u & ((1u << (8 * tail)) - 1u));
 	return c;
 }
-// flags[x] with its late bit (k_count keeps those in sub[])
-__device__ __forceinline__ uint32_t flag_with_late(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ sub, int64_t x)
+// anchor x's flag byte as the compaction sees it: a singleton's from the masks, the late bit from sub[] (k_count)
+__device__ __forceinline__ uint32_t flag_with_late(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ sub,
+                                                   const uint64_t *__restrict__ single_mask, const uint64_t *__restrict__ emit_mask, int64_t x)
 {
+	if ((single_mask[x >> 6] >> (x & 63)) & 1u) return 0x20u | (((emit_mask[x >> 6] >> (x & 63)) & 1u) ? 0x0au : 0u);
 	return ((uint32_t)flags[x] & ~1u) | ((sub[x >> 4] >> (16 + (int)(x & 15))) & 1u);     // (a block is 64 runs of 16: sub[] is indexed by x / 16)
 }
 
@@ -254,7 +279,8 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_emit_seeds(Params par, int64_t n_
                                                           const int32_t *__restrict__ first_child,
                                                           const unsigned long long *__restrict__ block_base,
                                                           int64_t *__restrict__ seeds_off, SeedRec *__restrict__ seeds,
-                                                          const int2 *__restrict__ block_reads, const uint32_t *__restrict__ sub)
+                                                          const int2 *__restrict__ block_reads, const uint32_t *__restrict__ sub,
+                                                          const uint64_t *__restrict__ single_mask, const uint64_t *__restrict__ emit_mask)
 {
 	__shared__ uint32_t s_pos[CMP_PER_BLOCK];                        // position of the first record an anchor emits (were it to emit any)
 	__shared__ uint8_t s_fl[CMP_PER_BLOCK];
@@ -272,6 +298,7 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_emit_seeds(Params par, int64_t n_
 	if (g < g1) {
 		const uint32_t l4 = (sub[g >> 4] >> (16 + (int)(g & 15))) & 0xfu;           // the late bits of the four (k_count)
 		w = (*(const uint32_t*)(flags + g) & ~0x01010101u) | (l4 & 1u) | (l4 & 2u) << 7 | (l4 & 4u) << 14 | (l4 & 8u) << 21;
+		w = flags_with_singles(w, mask_bits16(single_mask, g) & 0xfu, mask_bits16(emit_mask, g) & 0xfu);
 		n = g1 - g < 4 ? (int)(g1 - g) : 4;
 		if (n < 4) w &= (1u << (8 * n)) - 1u;
 	}
@@ -281,7 +308,7 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_emit_seeds(Params par, int64_t n_
 	if (lane == 63) s_wsum[wave] = incl;
 	if (threadIdx.x == 0) {
 		const int64_t rs = off[rlo];
-		s_so_lo = rs >= g0 ? 0xffffffffu : pos_before(flags, block_base, sub, rs);    // (a read that starts in this block: from s_pos below)
+		s_so_lo = rs >= g0 ? 0xffffffffu : pos_before(flags, block_base, sub, single_mask, emit_mask, rs);    // (a read that starts in this block: from s_pos below)
 	}
 	__syncthreads();
 	uint32_t pos = (uint32_t)block_base[blockIdx.x] + incl - mine;
@@ -293,8 +320,8 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_emit_seeds(Params par, int64_t n_
 	}
 	__syncthreads();
 	// position of the first record of anchor x (batch-global index; x <= the block's last anchor)
-	auto pos_of = [&](int64_t x) -> uint32_t { return x >= g0 ? s_pos[x - g0] : pos_before(flags, block_base, sub, x); };
-	auto flag_of = [&](int64_t x) -> uint32_t { return x >= g0 ? (uint32_t)s_fl[x - g0] : flag_with_late(flags, sub, x); };
+	auto pos_of = [&](int64_t x) -> uint32_t { return x >= g0 ? s_pos[x - g0] : pos_before(flags, block_base, sub, single_mask, emit_mask, x); };
+	auto flag_of = [&](int64_t x) -> uint32_t { return x >= g0 ? (uint32_t)s_fl[x - g0] : flag_with_late(flags, sub, single_mask, emit_mask, x); };
 	// records: a thread per anchor, consecutive lanes on consecutive anchors (their records are consecutive too: the stores of a
 	// wave are contiguous)
 	for (int64_t ge = g0 + threadIdx.x; ge < g1; ge += CMP_BLOCK) {
@@ -304,8 +331,10 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_emit_seeds(Params par, int64_t n_
 		const int64_t rs = off[r];
 		if (ge == rs) for (int64_t q = r; q >= 0 && off[q] == rs; --q) seeds_off[q] = (int64_t)mypos;   // (empty reads in front share the value)
 		if (!(fl & 2)) continue;                                       // not emitted at its own step
-		const uint32_t so = rs >= g0 ? s_pos[rs - g0] : (r == rlo ? s_so_lo : pos_before(flags, block_base, sub, rs));
-		const int32_t q = p[ge], fk = f[ge];
+		const uint32_t so = rs >= g0 ? s_pos[rs - g0] : (r == rlo ? s_so_lo : pos_before(flags, block_base, sub, single_mask, emit_mask, rs));
+		const ulonglong2 ak = a[ge];
+		int32_t q = p[ge], fk = f[ge];
+		if (fl & 0x20u) { q = -1; fk = (int32_t)((uint32_t)(ak.y >> 32) & 0xffu); }   // a singleton (nobody stored its p and f): chain.c:251,283 with an empty window
 		const uint32_t idk = mypos + (fl & 1);
 		int32_t pfield = (int32_t)(0xfffffffcu);                       // (-1)<<2
 		if (q >= 0) {
@@ -324,7 +353,6 @@ __global__ __launch_bounds__(CMP_BLOCK) void k_emit_seeds(Params par, int64_t n_
 			const uint32_t idq = (fl & 1) ? idk - 1 : (flq & 2) ? pos_of(qg) + (flq & 1) : pos_of(rs + first_child[qg]);
 			pfield = (int32_t)((idq - so) << 2);                       // chain.c:310, read-relative index
 		}
-		const ulonglong2 ak = a[ge];
 		SeedRec rec;
 		rec.x = ak.x; rec.y = ak.y; rec.f = fk;
 		rec.p = pfield | ((fl >> 3) & 3);                              // chain.c:313-314: (v >= min_sc) | (f < v) << 1, from the DP kernel
@@ -360,10 +388,10 @@ hipError_t launch_compact(hipStream_t st, const Params &par, int64_t n_reads, in
 	const dim3 g((unsigned)blocks), b(CMP_BLOCK);
 	const int64_t cw = (blocks + CNT_BLOCKS_PER_WAVE - 1) / CNT_BLOCKS_PER_WAVE;    // waves of k_count
 	const dim3 gc((unsigned)((cw + CMP_BLOCK / 64 - 1) / (CMP_BLOCK / 64)));
-	hipLaunchKernelGGL(k_count, gc, b, 0, st, n_reads, total, d_off, d_p, d_first_child, sc.flags, sc.block_cnt, sc.block_reads, sc.sub);
+	hipLaunchKernelGGL(k_count, gc, b, 0, st, n_reads, total, d_off, d_p, d_first_child, sc.flags, sc.block_cnt, sc.block_reads, sc.sub, sc.single_mask, sc.emit_mask);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, sc.n_seeds)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_emit_seeds, g, b, 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a, d_f, d_p, d_v, sc.flags, d_first_child,
-	                   sc.block_cnt, d_seeds_off, (SeedRec*)d_seeds, sc.block_reads, sc.sub);
+	                   sc.block_cnt, d_seeds_off, (SeedRec*)d_seeds, sc.block_reads, sc.sub, sc.single_mask, sc.emit_mask);
 	hipLaunchKernelGGL(k_finish_offsets, dim3(1), dim3(1), 0, st, n_reads, total, d_off, sc.n_seeds, d_seeds_off);
 	return hipGetLastError();
 }

@@ -33,7 +33,9 @@ struct UnitAux {
 
 // prepass scratch: one 64-bit unit-start mask per 64 anchors, per-block unit / singleton counts
 struct PrepassScratch {
-	uint64_t *start_mask;
+	uint64_t *start_mask;            // per 64 anchors: the unit starts among them
+	uint64_t *single_mask;           // the singletons (anchors with an empty window whose successor starts anew: f = v = q_span, p = -1) ...
+	uint64_t *emit_mask;             // ... and those of them that are emitted (q_span >= min_sc, chain.c:304)
 	unsigned long long *block_cnt;   // per 1024-anchor block: units | singletons << 32; scanned in place
 	unsigned long long *tile_tmp;    // scratch of the scan
 	Unit *units_tmp;                 // units in anchor order, before the longest-first scatter
@@ -46,7 +48,10 @@ size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *bl
 // counters[0] = units emitted (low 32 bits) | singleton anchors resolved by the prepass (high 32 bits)
 hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off, const void *d_a,
                           unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
-                          int32_t *d_f, int32_t *d_p, int32_t *d_v, uint8_t *d_flags, UnitAux *d_unit_aux = nullptr);
+                          UnitAux *d_unit_aux = nullptr);
+// f, p, v, flags[] of the batch's singletons (the prepass only marks them; the compaction reads the marks)
+hipError_t launch_fill_singles(hipStream_t st, const Params &par, int64_t total, const void *d_a, PrepassScratch sc,
+                               int32_t *d_f, int32_t *d_p, int32_t *d_v, uint8_t *d_flags);
 
 // Per-read gap-cost table (uint16), lut_stride entries per read (multiple of 8); usable while
 // bw <= CHAINDP_LUT_MAX_BW.  d_lut == nullptr makes every unit take the general (f64) variant.
@@ -115,6 +120,7 @@ struct CompactScratch {
 	unsigned long long *tile_tmp;
 	unsigned long long *n_seeds;     // total records of the batch
 	const int2 *block_reads;         // PrepassScratch::block_reads of the same batch
+	const uint64_t *single_mask, *emit_mask;   // PrepassScratch's: flags[] of a singleton is whatever an earlier batch left there
 	uint32_t *sub;                   // per run of 16 anchors (64 per 1024-anchor block; k_count): low half = records of the block in front
 	                                 // of the run, high half = the late bits of its 16 anchors
 };

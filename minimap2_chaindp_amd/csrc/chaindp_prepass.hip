@@ -3,8 +3,10 @@
 // per-read gap-cost table.  See chaindp_kernels.hip for the overall scheme.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "chaindp_kernels.h"
 #include "chaindp_wave.h"
+#include "chaindp_lanes.h"
 
 namespace chaindp {
 
@@ -53,50 +55,83 @@ __global__ __launch_bounds__(256) void k_block_reads(int64_t n_reads, int64_t to
 // short burst in flight per wave, then its dependent loads of the read's bounds, a block-wide reduction and the end of the
 // workgroup: 3.3 TB/s with neither the vector nor the scalar pipe busy).  What a tile needs from its neighbours comes out of
 // registers -- the last x of the tile before, the first x of the tile after, already loaded -- and the read's bounds, the counts
-// and the q_span sum are wave-uniform state carried from tile to tile: no LDS, no barrier, one 128-byte store of the block's
-// sixteen start masks, one atomic per block and read.
+// and the q_span sum are wave-uniform state carried from tile to tile, read boundaries inside a tile included (lane ranges, no
+// per-lane search): no LDS, no barrier, one 128-byte store of the block's sixteen start masks, one atomic per block and read.
+//
+// The tile loads of a full block are issued and awaited by hand.  The compiler counts the conditional stores of the singletons
+// into its bookkeeping of outstanding vector memory operations and ends up waiting for ALL of them (s_waitcnt vmcnt(0)) before every
+// tile, i.e. for the load it has just issued: one tile in flight per wave, 3.9 TB/s.  Loads return in order, so waiting until at
+// most (tile loads issued after the one needed) operations are outstanding is safe whatever stores sit between them.
 #define PW_TILES (PRE_PER_BLOCK / 64)
-#define PW_DEPTH 4                                                   // tiles requested ahead of the one in hand
+#define PW_DEPTH 6                                                   // tiles requested ahead of the one in hand
+
+typedef uint32_t pw_u32x4 __attribute__((ext_vector_type(4)));       // an anchor: x.lo, x.hi, y.lo, y.hi
+
+// largest r in [lo, hi] with off[r] <= g for wave-uniform arguments; off[] through the scalar cache
+__device__ __forceinline__ int64_t read_of_uniform(const int64_t *__restrict__ off, int64_t lo, int64_t hi, int64_t g)
+{
+	while (lo < hi) {
+		const int64_t mid = (lo + hi + 1) >> 1;
+		if (*TW_CONST(int64_t, off + mid) <= g) lo = mid; else hi = mid - 1;
+	}
+	return lo;
+}
+
+template <int N>
+__device__ __forceinline__ void pw_wait(pw_u32x4 &q0, pw_u32x4 &q1)     // both tiles have arrived once at most N later operations are outstanding
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("s_waitcnt vmcnt(%2)" : "+v"(q0), "+v"(q1) : "n"(N));
+#endif
+}
 
 template <bool FULL>                                                 // FULL: all 1024 anchors exist (every block but the batch's last)
 __device__ __forceinline__ void prepass_block(const Params &par, const int64_t b, const int lane, const int64_t total,
                                               const int64_t *__restrict__ off, const ulonglong2 *__restrict__ a,
                                               unsigned long long *__restrict__ sumq, uint64_t *__restrict__ start_mask,
-                                              unsigned long long *__restrict__ block_cnt,
-                                              int32_t *__restrict__ f, int32_t *__restrict__ p, int32_t *__restrict__ v,
-                                              uint8_t *__restrict__ flags, const int2 *__restrict__ block_reads)
+                                              uint64_t *__restrict__ single_mask, uint64_t *__restrict__ emit_mask,
+                                              unsigned long long *__restrict__ block_cnt, const int2 *__restrict__ block_reads)
 {
 	const uint64_t maxx = (uint64_t)(int64_t)par.max_dist_x;
 	const int64_t g0 = b * PRE_PER_BLOCK;
 	const int64_t g1 = FULL ? g0 + PRE_PER_BLOCK : total;
 	const int n_in = FULL ? PRE_PER_BLOCK : (int)(g1 - g0);          // anchors of the block
 	const int nt = (n_in + 63) >> 6;                                 // tiles of the block
-	const ulonglong2 *const ab = a + g0 + lane;
-	ulonglong2 an_[PW_DEPTH];
+	const uint32_t voff = (uint32_t)lane * 16u;
+	pw_u32x4 q[PW_TILES];
+	auto request = [&](int t) {                                      // tile t of the block -> q[t]
+		if (FULL) {
+#if defined(__HIP_DEVICE_COMPILE__)
+			const ulonglong2 *const base = a + g0 + (t & ~3) * 64;       // (the instruction's offset field reaches four tiles)
+			if ((t & 3) == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q[t]) : "v"(voff), "s"(base) : "memory");
+			else if ((t & 3) == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(q[t]) : "v"(voff), "s"(base) : "memory");
+			else if ((t & 3) == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(q[t]) : "v"(voff), "s"(base) : "memory");
+			else asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(q[t]) : "v"(voff), "s"(base) : "memory");
+#endif
+		} else {                                                     // the batch's last block: plain loads, the compiler's own waits
+			q[t] = (pw_u32x4)(0u);                                   // (an anchor that does not exist: x = 0, q_span = 0, no segment id)
+			if (t * 64 + lane < n_in) q[t] = *(const pw_u32x4*)(a + g0 + t * 64 + lane);
+		}
+	};
 #pragma unroll
-	for (int k = 0; k < PW_DEPTH; ++k) {
-		an_[k] = make_ulonglong2(0, 0);                              // (an anchor that does not exist: x = 0, q_span = 0, no segment id)
-		if (FULL || k * 64 + lane < n_in) an_[k] = ab[k * 64];
-	}
-	const int2 rr = block_reads[b];                                  // reads of the block's first and last anchor (k_block_reads)
-	uint64_t x_carry = g0 > 0 ? a[g0 - 1].x : 0;                     // x of the anchor before the tile in hand (wave-uniform)
-	const uint64_t x_after = g1 < total ? a[g1].x : 0;               // x of the anchor after the block
-	// the read the tile in hand starts in, its bounds relative to the block (32-bit: the scalar unit compares no 64-bit order):
+	for (int k = 0; k < PW_DEPTH; ++k) request(k);
+	const int2 rr = *TW_CONST(int2, block_reads + b);                // reads of the block's first and last anchor (k_block_reads)
+	uint64_t x_carry = g0 > 0 ? *TW_CONST(uint64_t, &a[g0 - 1].x) : 0;   // x of the anchor before the tile in hand (wave-uniform)
+	const uint64_t x_after = g1 < total ? *TW_CONST(uint64_t, &a[g1].x) : 0;   // x of the anchor after the block
+	// the read the tile in hand lies in, its bounds relative to the block (32-bit: the scalar unit compares no 64-bit order):
 	// rs_b < 0 when it starts before the block, re_b capped when it ends far behind it
 	int64_t r_cur = rr.x;
-	auto bounds = [&](int &rs_b, int &re_b) {
-		const int64_t ds = off[r_cur] - g0, de = off[r_cur + 1] - g0;
+	int rs_b, re_b;
+	auto bounds = [&]() {
+		const int64_t ds = *TW_CONST(int64_t, off + r_cur) - g0, de = *TW_CONST(int64_t, off + r_cur + 1) - g0;
 		rs_b = ds < 0 ? -1 : (int)ds;
 		re_b = ((uint64_t)de >> 20) ? 1 << 20 : (int)de;
 	};
-	int rs_b, re_b;
-	bounds(rs_b, re_b);
+	bounds();
 	unsigned int w_sum = 0, any_seg = 0;                             // per lane, of r_cur
 	uint64_t span0_m = 0;                                            // lanes that saw a zero q_span in r_cur
 	unsigned int n_units = 0, n_singles = 0;                         // wave-uniform
-	uint32_t mk_lo = 0, mk_hi = 0;                                   // lane t: the start mask of tile t
-	int32_t *fb = f + g0 + lane, *pb = p + g0 + lane, *vb = v + g0 + lane;
-	uint8_t *flb = flags + g0 + lane;
+	uint32_t mk_lo = 0, mk_hi = 0, sk_lo = 0, sk_hi = 0, ek_lo = 0, ek_hi = 0;   // lane t: tile t's unit starts, singletons, emitted singletons
 	auto flush = [&]() {                                             // r_cur's share of the block is complete
 		unsigned int s = w_sum;
 		for (int d = 32; d; d >>= 1) s += __shfl_xor(s, d, 64);
@@ -105,96 +140,118 @@ __device__ __forceinline__ void prepass_block(const Params &par, const int64_t b
 		if (span0_m && lane == 0) atomicOr(&sumq[r_cur], SUMQ_SPAN0_FLAG);                                      // (never, in minimap2's own anchors)
 		w_sum = 0; any_seg = 0; span0_m = 0;
 	};
-#pragma unroll 1
-	for (int t0 = 0; t0 < PW_TILES; t0 += PW_DEPTH) {
-#pragma unroll
-		for (int j = 0; j < PW_DEPTH; ++j) {
-			const int t = t0 + j, tb = t * 64;                           // the tile and its place in the block
-			if (!FULL && t >= nt) break;
-			const int in_tile = FULL ? 64 : (n_in - tb < 64 ? n_in - tb : 64);
-			const uint64_t have_m = FULL || in_tile == 64 ? ~0ull : (1ull << in_tile) - 1;
-			const ulonglong2 an = an_[j];
-			uint64_t x_follow = x_after;
-			if (t + 1 < (FULL ? PW_TILES : nt)) x_follow = readlane_u64(an_[(j + 1) % PW_DEPTH].x, 0);
-			const uint32_t xlo = (uint32_t)an.x, xhi = (uint32_t)(an.x >> 32);
-			const uint32_t plo = (uint32_t)dpp_or_old<DPP_WAVE_SHR1, 0xf>((int)(uint32_t)x_carry, (int)xlo);          // lane 0 keeps the carry
-			const uint32_t phi = (uint32_t)dpp_or_old<DPP_WAVE_SHR1, 0xf>((int)(uint32_t)(x_carry >> 32), (int)xhi);
-			const uint32_t nlo = (uint32_t)dpp_or_old<DPP_WAVE_SHL1, 0xf>((int)(uint32_t)x_follow, (int)xlo);         // lane 63 keeps what follows
-			const uint32_t nhi = (uint32_t)dpp_or_old<DPP_WAVE_SHL1, 0xf>((int)(uint32_t)(x_follow >> 32), (int)xhi);
-			const uint64_t xprev = (uint64_t)phi << 32 | plo, xnext = (uint64_t)nhi << 32 | nlo;
-			const uint32_t yhi = (uint32_t)(an.y >> 32);
-			const int span = (int)(yhi & 0xffu);
-			if (tb >= re_b) {                                            // the tile starts in a later read
+	auto tile = [&](auto tile_index) {                               // (a constant per call: the waits and lane selects below are immediates)
+		constexpr int t = decltype(tile_index)::value;
+		if (!FULL && t >= nt) return;
+		const int tb = t * 64;                                       // the tile's place in the block
+		const int in_tile = FULL ? 64 : (n_in - tb < 64 ? n_in - tb : 64);
+		const uint64_t have_m = FULL || in_tile == 64 ? ~0ull : (1ull << in_tile) - 1;
+		constexpr int LAST = PW_TILES - 1;
+		constexpr int newest = t + PW_DEPTH - 1 < LAST ? t + PW_DEPTH - 1 : LAST, need = t < LAST ? t + 1 : LAST;
+		if (FULL) pw_wait<newest - need>(q[t], q[need]);
+		const pw_u32x4 an = q[t];
+#ifdef PW_EXP_LOADONLY
+		any_seg ^= an.x ^ an.w;
+		if (t + PW_DEPTH < PW_TILES && (FULL || t + PW_DEPTH < nt)) request(t + PW_DEPTH);
+		return;
+#endif
+		uint64_t x_follow = x_after;
+		if (t + 1 < PW_TILES && (FULL || t + 1 < nt)) x_follow = readlane_u64((uint64_t)q[need].y << 32 | q[need].x, 0);
+		const uint32_t plo = (uint32_t)dpp_or_old<DPP_WAVE_SHR1, 0xf>((int)(uint32_t)x_carry, (int)an.x);          // lane 0 keeps the carry
+		const uint32_t phi = (uint32_t)dpp_or_old<DPP_WAVE_SHR1, 0xf>((int)(uint32_t)(x_carry >> 32), (int)an.y);
+		const uint32_t nlo = (uint32_t)dpp_or_old<DPP_WAVE_SHL1, 0xf>((int)(uint32_t)x_follow, (int)an.x);         // lane 63 keeps what follows
+		const uint32_t nhi = (uint32_t)dpp_or_old<DPP_WAVE_SHL1, 0xf>((int)(uint32_t)(x_follow >> 32), (int)an.y);
+		const uint64_t x = (uint64_t)an.y << 32 | an.x, xprev = (uint64_t)phi << 32 | plo, xnext = (uint64_t)nhi << 32 | nlo;
+		const int span = (int)(an.w & 0xffu);
+		const uint32_t segbits = an.w & 0x00ff0000u;
+		// lane masks, combined by the scalar unit
+		const uint64_t far_prev = __builtin_amdgcn_uicmpl(x - xprev, maxx, 34), far_next = __builtin_amdgcn_uicmpl(xnext - x, maxx, 34);
+		const uint64_t zero_m = __builtin_amdgcn_uicmp((unsigned)span, 0u, 32) & have_m;
+		// the reads of the tile, one lane range after the other (usually one: the whole tile inside r_cur)
+		uint64_t start_x = 0, last_x = 0;                            // starts / ends forced by the reads' bounds
+		int seg_lo = 0;
+		for (;;) {
+			if (re_b <= tb + seg_lo) {                               // r_cur ends here: the range starts in a later read
 				flush();
-				r_cur = read_of(off, r_cur, rr.y, g0 + tb);
-				bounds(rs_b, re_b);
+				r_cur = read_of_uniform(off, r_cur, rr.y, g0 + tb + seg_lo);
+				bounds();
 			}
-			uint64_t start_m, single_m;
-			if (tb + in_tile <= re_b) {                                  // the whole tile lies in r_cur: the usual tile.  Lane masks, combined by the scalar unit
-				const uint64_t far_prev = __builtin_amdgcn_uicmpl(an.x - xprev, maxx, 34), far_next = __builtin_amdgcn_uicmpl(xnext - an.x, maxx, 34);
-				const int l_re = re_b - tb;                                // the read ends before lane l_re of this tile (>= in_tile)
-				const uint64_t last_m = l_re <= 64 ? 1ull << (l_re - 1) : 0ull;
-				start_m = (far_prev | (rs_b == tb ? 1ull : 0ull)) & have_m;
-				single_m = start_m & (far_next | last_m);
-				span0_m |= __builtin_amdgcn_uicmp((unsigned)span, 0u, 32) & have_m;
-				any_seg |= yhi & 0x00ff0000u;
-				w_sum += (unsigned int)span;
-			} else {                                                     // a read ends inside the tile: every lane finds its own read
-				bool start = false, single = false;
-				if (FULL || lane < in_tile) {
-					const int64_t g = g0 + tb + lane;
-					const int64_t r = read_of(off, r_cur, rr.y, g);
-					const int64_t rs_l = off[r], re_l = off[r + 1];
-					start = g == rs_l || an.x - xprev > maxx;
-					single = start && (g + 1 >= re_l || xnext - an.x > maxx);
-					if (r == r_cur) {
-						any_seg |= yhi & 0x00ff0000u;
-						w_sum += (unsigned int)span;
-					} else {
-						if (yhi & 0x00ff0000u) atomicOr(&sumq[r], SUMQ_SEG_FLAG);
-						if (span) atomicAdd(&sumq[r], (unsigned long long)span);
-					}
-					if (span == 0) atomicOr(&sumq[r], SUMQ_SPAN0_FLAG);
-				}
-				start_m = __builtin_amdgcn_ballot_w64(start);
-				single_m = __builtin_amdgcn_ballot_w64(single);
+			if (rs_b == tb + seg_lo) start_x |= 1ull << seg_lo;
+			const int l_re = re_b - tb;                              // r_cur ends in front of this lane of the tile (> seg_lo)
+			const int seg_hi = l_re < in_tile ? l_re : in_tile;
+			if (l_re <= 64) last_x |= 1ull << (l_re - 1);
+			if (seg_lo == 0 && seg_hi == 64) {
+				w_sum += (unsigned int)span; any_seg |= segbits; span0_m |= zero_m;
+			} else {                                                 // lanes [seg_lo, seg_hi) are r_cur's
+				const uint64_t m = ((seg_hi == 64 ? 0ull : 1ull << seg_hi) - 1ull) & (~0ull << seg_lo);
+				const bool mine = __builtin_amdgcn_inverse_ballot_w64(m);
+				w_sum += mine ? (unsigned int)span : 0u; any_seg |= mine ? segbits : 0u; span0_m |= zero_m & m;
 			}
-			if (__builtin_amdgcn_inverse_ballot_w64(single_m)) {         // chain.c:251,283-284 with an empty window
-				fb[j * 64] = span; pb[j * 64] = -1; vb[j * 64] = span;
-				flb[j * 64] = (uint8_t)(span >= par.min_sc ? 2 | 8 : 0);    // emitted at its own step iff v >= min_sc (chain.c:304); bit3 = v >= min_sc
-			}
-			const uint64_t em = start_m & ~single_m;
-			n_units += (unsigned int)__builtin_popcountll(em);
-			n_singles += (unsigned int)__builtin_popcountll(single_m);
-			asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"           // (one SGPR and M0 per instruction: the constant bus)
-			    : "+v"(mk_lo), "+v"(mk_hi) : "s"((uint32_t)em), "s"(t), "s"((uint32_t)(em >> 32)) : "m0");
-			x_carry = readlane_u64(an.x, 63);                            // (a tile that is not full is the last one)
-			if (t0 + PW_DEPTH < PW_TILES) {                              // its slot takes the tile PW_DEPTH further on
-				an_[j] = make_ulonglong2(0, 0);
-				if (FULL || tb + PW_DEPTH * 64 + lane < n_in) an_[j] = ab[tb + PW_DEPTH * 64];
-			}
+			if (seg_hi >= in_tile) break;
+			seg_lo = seg_hi;
 		}
-		fb += PW_DEPTH * 64; pb += PW_DEPTH * 64; vb += PW_DEPTH * 64; flb += PW_DEPTH * 64;
-	}
+		const uint64_t start_m = (far_prev | start_x) & have_m;
+		const uint64_t single_m = start_m & (far_next | last_x);
+		// a singleton's results (chain.c:251,283-284 with an empty window: f = v = q_span, p = -1; emitted at its own step iff
+		// v >= min_sc, chain.c:304) are not stored here: two masks say which anchors are singletons and which of those are emitted,
+		// the compaction reads them beside flags[], and k_fill_singles writes f, p, v, flags for callers that look at those arrays
+		// (104 M scattered partial stores on the 100k-read job cost the kernel a third of its time: 2.0 -> 2.9 ms)
+		const uint64_t emit_m = single_m & __builtin_amdgcn_sicmp(span, par.min_sc, 39);
+		const uint64_t em = start_m & ~single_m;
+		n_units += (unsigned int)__builtin_popcountll(em);
+		n_singles += (unsigned int)__builtin_popcountll(single_m);
+#if defined(__HIP_DEVICE_COMPILE__)
+		asm("v_writelane_b32 %0, %1, %2" : "+v"(mk_lo) : "s"((uint32_t)em), "n"(t));
+		asm("v_writelane_b32 %0, %1, %2" : "+v"(mk_hi) : "s"((uint32_t)(em >> 32)), "n"(t));
+		asm("v_writelane_b32 %0, %1, %2" : "+v"(sk_lo) : "s"((uint32_t)single_m), "n"(t));
+		asm("v_writelane_b32 %0, %1, %2" : "+v"(sk_hi) : "s"((uint32_t)(single_m >> 32)), "n"(t));
+		asm("v_writelane_b32 %0, %1, %2" : "+v"(ek_lo) : "s"((uint32_t)emit_m), "n"(t));
+		asm("v_writelane_b32 %0, %1, %2" : "+v"(ek_hi) : "s"((uint32_t)(emit_m >> 32)), "n"(t));
+#endif
+		x_carry = readlane_u64(x, 63);                               // (a tile that is not full is the last one)
+		if (t + PW_DEPTH < PW_TILES && (FULL || t + PW_DEPTH < nt)) request(t + PW_DEPTH);
+		__builtin_amdgcn_sched_barrier(0);                           // tiles one after the other: interleaved, their masks run the scalar registers out
+	};
+	tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{}); tile(std::integral_constant<int, 2>{}); tile(std::integral_constant<int, 3>{});
+	tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{}); tile(std::integral_constant<int, 6>{}); tile(std::integral_constant<int, 7>{});
+	tile(std::integral_constant<int, 8>{}); tile(std::integral_constant<int, 9>{}); tile(std::integral_constant<int, 10>{}); tile(std::integral_constant<int, 11>{});
+	tile(std::integral_constant<int, 12>{}); tile(std::integral_constant<int, 13>{}); tile(std::integral_constant<int, 14>{}); tile(std::integral_constant<int, 15>{});
 	flush();
-	if (lane < nt) start_mask[(g0 >> 6) + lane] = (uint64_t)mk_hi << 32 | mk_lo;
+	if (lane < nt) {
+		start_mask[(g0 >> 6) + lane] = (uint64_t)mk_hi << 32 | mk_lo;
+		single_mask[(g0 >> 6) + lane] = (uint64_t)sk_hi << 32 | sk_lo;
+		emit_mask[(g0 >> 6) + lane] = (uint64_t)ek_hi << 32 | ek_lo;
+	}
 	if (lane == 0) block_cnt[b] = (unsigned long long)n_singles << 32 | n_units;   // two counters, one scan
 }
 
 __global__ __launch_bounds__(PRE_BLOCK) void k_prepass(Params par, int64_t n_reads, int64_t total,
                                                        const int64_t *__restrict__ off, const ulonglong2 *__restrict__ a,
                                                        unsigned long long *__restrict__ sumq, uint64_t *__restrict__ start_mask,
-                                                       unsigned long long *__restrict__ block_cnt,
-                                                       int32_t *__restrict__ f, int32_t *__restrict__ p, int32_t *__restrict__ v,
-                                                       uint8_t *__restrict__ flags,
-                                                       const int2 *__restrict__ block_reads)
+                                                       uint64_t *__restrict__ single_mask, uint64_t *__restrict__ emit_mask,
+                                                       unsigned long long *__restrict__ block_cnt, const int2 *__restrict__ block_reads)
 {
 	const int lane = threadIdx.x & 63;
 	const int64_t b = (int64_t)blockIdx.x * (PRE_BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const int64_t g0 = b * PRE_PER_BLOCK;
 	if (g0 >= total) return;
-	if (g0 + PRE_PER_BLOCK <= total) prepass_block<true>(par, b, lane, total, off, a, sumq, start_mask, block_cnt, f, p, v, flags, block_reads);
-	else prepass_block<false>(par, b, lane, total, off, a, sumq, start_mask, block_cnt, f, p, v, flags, block_reads);
+	if (g0 + PRE_PER_BLOCK <= total) prepass_block<true>(par, b, lane, total, off, a, sumq, start_mask, single_mask, emit_mask, block_cnt, block_reads);
+	else prepass_block<false>(par, b, lane, total, off, a, sumq, start_mask, single_mask, emit_mask, block_cnt, block_reads);
+}
+
+// f, p, v and flags[] of the singletons, from the prepass' masks: for callers that read those arrays (chaindp_download, a run on the
+// caller's own device arrays).  The compaction does not need it.
+__global__ __launch_bounds__(256) void k_fill_singles(int64_t total, int min_sc, const ulonglong2 *__restrict__ a,
+                                                      const uint64_t *__restrict__ single_mask,
+                                                      int32_t *__restrict__ f, int32_t *__restrict__ p, int32_t *__restrict__ v,
+                                                      uint8_t *__restrict__ flags)
+{
+	for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+		if (!((single_mask[g >> 6] >> (g & 63)) & 1u)) continue;
+		const int span = span_of_hi((uint32_t)(a[g].y >> 32));
+		f[g] = span; p[g] = -1; v[g] = span;
+		flags[g] = (uint8_t)(span >= min_sc ? 2 | 8 : 0);
+	}
 }
 
 // Units are scheduled longest first (a unit is one wave's serial work, so a long one started last would be the
@@ -351,7 +408,7 @@ __global__ __launch_bounds__(256) void k_build_lut(Params par, int64_t n_reads, 
 
 hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off, const void *d_a,
                           unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
-                          int32_t *d_f, int32_t *d_p, int32_t *d_v, uint8_t *d_flags, UnitAux *d_unit_aux)
+                          UnitAux *d_unit_aux)
 {
 	hipError_t e = hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st);
 	if (e != hipSuccess || n_reads <= 0 || total <= 0) return e;
@@ -360,7 +417,7 @@ hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, in
 	const int64_t words = (total + 63) / 64;
 	hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, st, n_reads, total, d_off, sc.block_reads);
 	hipLaunchKernelGGL(k_prepass, dim3((unsigned)((blocks + PRE_BLOCK / 64 - 1) / (PRE_BLOCK / 64))), dim3(PRE_BLOCK), 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a,
-	                   d_sumq, sc.start_mask, sc.block_cnt, d_f, d_p, d_v, d_flags, sc.block_reads);
+	                   d_sumq, sc.start_mask, sc.single_mask, sc.emit_mask, sc.block_cnt, sc.block_reads);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, d_counters)) != hipSuccess) return e;
 	if ((e = hipMemsetAsync(sc.hist, 0, 2 * UNIT_CLASSES * sizeof(unsigned int), st)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_emit_units, dim3((unsigned)((words + 255) / 256 < 2048 ? (words + 255) / 256 : 2048)), dim3(256), 0, st, n_reads, words, d_off,
@@ -368,6 +425,16 @@ hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, in
 	hipLaunchKernelGGL(k_unit_bases, dim3(1), dim3(64), 0, st, sc.hist, sc.hist + UNIT_CLASSES, d_unit_aux ? sc.key_range : nullptr);
 	hipLaunchKernelGGL(k_unit_scatter, dim3((unsigned)(blocks < 1024 ? (blocks > 0 ? blocks : 1) : 1024)), dim3(256), 0, st, d_counters, sc.units_tmp,
 	                   sc.hist, sc.hist + UNIT_CLASSES, d_units, par, d_off, d_sumq, d_unit_aux, d_unit_aux ? sc.key_range : nullptr);
+	return hipGetLastError();
+}
+
+hipError_t launch_fill_singles(hipStream_t st, const Params &par, int64_t total, const void *d_a, PrepassScratch sc,
+                               int32_t *d_f, int32_t *d_p, int32_t *d_v, uint8_t *d_flags)
+{
+	if (total <= 0) return hipSuccess;
+	const int64_t blocks = (total + 255) / 256;
+	hipLaunchKernelGGL(k_fill_singles, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, total, par.min_sc, (const ulonglong2*)d_a,
+	                   sc.single_mask, d_f, d_p, d_v, d_flags);
 	return hipGetLastError();
 }
 
