@@ -185,6 +185,7 @@ def main():
                 "limited_by": "VALU instruction issue (see issue)", "issue": measured_issue(total, dp_ms),
             },
             "kernel_ms": {"prepass": pre_ms, "chain_dp": dp_ms, "compact": cmp_ms},
+            "handed_over": {"to_one_unit_per_wave_kernel": dev.leftover_units(), "to_dense_kernel": dev.deep_units()},   # rank 0's last step
             "host": {"generate_s": t_gen, "upload_s": t_up, "upload_GBps": total * 16 / t_up / 1e9 if t_up > 0 else None},
         }
         out.update(extras)

@@ -254,7 +254,7 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		es.n = 3;
 	}
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[0], st));
-	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, ctx->d_unit_aux));
+	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, ctx->d_unit_aux, d_n_segs));
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[1], st));
 	// per-read gap-cost table for the fast variant (skipped when the table would not apply)
 	uint16_t *lut = nullptr;
@@ -279,16 +279,18 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 	HIP_TRY(ctx, hipMemsetAsync(ctx->d_left_cnt, 0, 4 * sizeof(unsigned long long), st));
 	Unit *const deep = ctx->deep_handover ? ctx->d_deep : nullptr;
 	unsigned int *const deep_cnt = (unsigned int*)(ctx->d_left_cnt + 1);
-	if (ctx->variant == 0 && lut && d_n_segs == nullptr) {
+	if (ctx->variant == 0 && lut) {
 		// ordinary units two per wave; what that kernel hands over (and nothing else) goes through k_chain_units
 		// (first_child[] is initialised by the DP kernels themselves, per tile: no batch-wide memset)
 		// four units per wave where the whole batch has one cost table, else two per wave: both are launched, the device decides
 		unsigned int *const route = (unsigned int*)(ctx->d_left_cnt + 3);
+		Params qt = q;                          // with per-read segment counts the units' UnitAux flags say which reads are multi-segment
+		if (d_n_segs) qt.n_segs = 1;            // (the batch-wide count is not used then, as in k_chain_units)
 		if (ctx->use_quad)
-			HIP_TRY(ctx, chaindp::launch_chain_quad(st, q, total / 2, d_a, lut, lut_stride, ctx->d_units, ctx->d_unit_aux, ctx->d_counters, ctx->pre.key_range,
+			HIP_TRY(ctx, chaindp::launch_chain_quad(st, qt, total / 2, d_a, lut, lut_stride, ctx->d_units, ctx->d_unit_aux, ctx->d_counters, ctx->pre.key_range,
 			                                        d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->d_left, (unsigned int*)ctx->d_left_cnt,
 			                                        (unsigned int*)ctx->d_left_cnt + 1, route, ctx->twin_force_left, total));
-		HIP_TRY(ctx, chaindp::launch_chain_twin(st, q, total / 2, d_off, d_a, ctx->d_sumq, lut, lut_stride, ctx->d_units, ctx->d_counters,
+		HIP_TRY(ctx, chaindp::launch_chain_twin(st, qt, total / 2, d_off, d_a, ctx->d_sumq, lut, lut_stride, ctx->d_units, ctx->d_counters,
 		                                        d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->d_left, (unsigned int*)ctx->d_left_cnt,
 		                                        ctx->twin_force_left, total, ctx->d_unit_aux, route));
 		const int64_t left_grid = total / 2 < 32768 ? total / 2 : 32768;
@@ -923,7 +925,8 @@ static int seed_reserve(chaindp_ctx *ctx, int64_t n_mini)
 		const size_t nr = (size_t)ctx->cap_reads;
 		void **slot[7] = {(void**)&ctx->d_mini_off, (void**)&ctx->d_mp_off, (void**)&ctx->d_bid, (void**)&ctx->d_qlen, (void**)&ctx->d_rep_len,
 		                  (void**)&ctx->seed.totals, (void**)&ctx->seed.stacks};
-		const size_t sz[7] = {(nr + 1) * 8, (nr + 1) * 8, (nr + 1) * 4, (nr + 1) * 4, (nr + 1) * 4, 32, ((size_t)ctx->cap_anchors / 64 + 2 * nr + 4) * 12};
+		const size_t stack_bytes = ((size_t)ctx->cap_anchors / 64 + 2 * nr + 4) * 12, tied_bytes = ((size_t)ctx->cap_anchors / 64 + nr + 8) * 4;
+		const size_t sz[7] = {(nr + 1) * 8, (nr + 1) * 8, (nr + 1) * 4, (nr + 1) * 4, (nr + 1) * 4, 32, stack_bytes + tied_bytes};
 		void *nb[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 		hipError_t e = hipSuccess;
 		for (int k = 0; k < 7 && e == hipSuccess; ++k) e = hipMalloc(&nb[k], sz[k]);
@@ -933,6 +936,7 @@ static int seed_reserve(chaindp_ctx *ctx, int64_t n_mini)
 			return CHAINDP_ERR_HIP;
 		}
 		for (int k = 0; k < 7; ++k) *slot[k] = nb[k];
+		ctx->seed.tied = (uint32_t*)((char*)ctx->seed.stacks + stack_bytes);
 		ctx->seed_ready = true;
 	}
 	if (n_mini > ctx->seed_cap_mini) {

@@ -48,7 +48,7 @@ size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *bl
 // counters[0] = units emitted (low 32 bits) | singleton anchors resolved by the prepass (high 32 bits)
 hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off, const void *d_a,
                           unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
-                          UnitAux *d_unit_aux = nullptr);
+                          UnitAux *d_unit_aux = nullptr, const int32_t *d_n_segs = nullptr);
 // f, p, v, flags[] of the batch's singletons (the prepass only marks them; the compaction reads the marks)
 hipError_t launch_fill_singles(hipStream_t st, const Params &par, int64_t total, const void *d_a, PrepassScratch sc,
                                int32_t *d_f, int32_t *d_p, int32_t *d_v, uint8_t *d_flags);
@@ -166,8 +166,9 @@ struct SeedScratch {                 // n = minimizers of the batch
 	unsigned long long *kept, *used; // n each: anchors / used minimizers per minimizer, scanned in place
 	unsigned long long *src, *mstate;// n each: where its hits are; hits | used << 32 | tandem << 33
 	unsigned long long *tile_tmp;    // scan scratch, n / 1024 + 2
-	unsigned long long *totals;      // 4: anchors, used minimizers, work items of the sort, spare
+	unsigned long long *totals;      // 4: anchors, used minimizers, work items of the sort, units of the sort with equal x
 	void *stacks;                    // (max_anchors / 64 + 2 R + 4) x 12 B: work items / range stacks of the per-read sort
+	uint32_t *tied;                  // max_anchors / 64 + R + 8: the sort's units (reads, then work items) that hold equal x
 };
 // phase 1: probe, scans, per-read offsets and rep_len; the host then reads off[n_reads] (capacity check) and runs
 // phase 2: expand (anchors in generation order into d_unsorted, mini_pos) and the per-read radix_sort_128x into d_a

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void k_unit_scatter(const unsigned long long *
                                                       const unsigned int *__restrict__ base, unsigned int *__restrict__ cursor,
                                                       Unit *__restrict__ out, Params par, const int64_t *__restrict__ off,
                                                       const unsigned long long *__restrict__ sumq, UnitAux *__restrict__ out_aux,
-                                                      unsigned int *__restrict__ key_range)
+                                                      unsigned int *__restrict__ key_range, const int32_t *__restrict__ n_segs_pr)
 {
 	__shared__ unsigned int s_cnt[UNIT_CLASSES], s_base[UNIT_CLASSES];
 	__shared__ unsigned int s_kmin, s_kmax;
@@ -364,7 +364,8 @@ __global__ __launch_bounds__(256) void k_unit_scatter(const unsigned long long *
 				const bool lut16 = 1 - ((int)((double)par.bw * .01 * (double)avg) + (lg >> 1)) < -128;   // the table's last entry (k_build_lut)
 				UnitAux ax;
 				ax.rel0 = (int32_t)(u[k].start - rs); ax.lutkey = __float_as_uint(avg);
-				ax.flags = ((sq & (SUMQ_SEG_FLAG | SUMQ_SPAN0_FLAG)) || lut16) ? 1u : 0u; ax.pad = 0;
+				const bool segs = n_segs_pr ? n_segs_pr[u[k].read] > 1 : par.n_segs > 1;   // (collect_task_t::n_segs, fpga_chaindp.h:53: the read's own count)
+				ax.flags = ((sq & (SUMQ_SEG_FLAG | SUMQ_SPAN0_FLAG)) || lut16 || segs) ? 1u : 0u; ax.pad = 0;
 				out_aux[pos] = ax;
 				if (ax.flags == 0) { kmin = ax.lutkey < kmin ? ax.lutkey : kmin; kmax = ax.lutkey > kmax ? ax.lutkey : kmax; }   // (avg_qspan > 0: its bits order like integers)
 			}
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256) void k_build_lut(Params par, int64_t n_reads, 
 
 hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off, const void *d_a,
                           unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
-                          UnitAux *d_unit_aux)
+                          UnitAux *d_unit_aux, const int32_t *d_n_segs)
 {
 	hipError_t e = hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st);
 	if (e != hipSuccess || n_reads <= 0 || total <= 0) return e;
@@ -424,7 +425,7 @@ hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, in
 	                   sc.start_mask, sc.block_cnt, sc.units_tmp, sc.hist, sc.block_reads);
 	hipLaunchKernelGGL(k_unit_bases, dim3(1), dim3(64), 0, st, sc.hist, sc.hist + UNIT_CLASSES, d_unit_aux ? sc.key_range : nullptr);
 	hipLaunchKernelGGL(k_unit_scatter, dim3((unsigned)(blocks < 1024 ? (blocks > 0 ? blocks : 1) : 1024)), dim3(256), 0, st, d_counters, sc.units_tmp,
-	                   sc.hist, sc.hist + UNIT_CLASSES, d_units, par, d_off, d_sumq, d_unit_aux, d_unit_aux ? sc.key_range : nullptr);
+	                   sc.hist, sc.hist + UNIT_CLASSES, d_units, par, d_off, d_sumq, d_unit_aux, d_unit_aux ? sc.key_range : nullptr, d_n_segs);
 	return hipGetLastError();
 }
 

@@ -448,6 +448,7 @@ __global__ __launch_bounds__(256) void k_seed_sort_huge(int64_t n_reads, int min
 // chosen per read inside one launch.
 // A queue keeps its first n / 65 + 2 slots for ranges of more than 64 anchors (they are disjoint, so they always fit);
 // small ranges that find the rest full are insertion-sorted on the spot by the lane that made them.
+#define SEED_TPB_C 1024                 // threads of the per-read sort's workgroup (SEED_TPB below)
 struct SeedRange { uint16_t beg, end; uint16_t shift, pad; };
 __host__ __device__ inline int seed_big_slots(int max_n) { return max_n / 65 + 2; }                    // queue slots for ranges of > 64 anchors: they are disjoint
 __host__ __device__ inline int seed_small_slots(int workers) { return workers >= 32 ? 1024 : 256; }   // queue slots for ranges of <= 64 anchors
@@ -464,6 +465,89 @@ __device__ __forceinline__ void seed_isort(uint64_t *key, uint16_t *idx, int beg
 	}
 }
 
+// Least-significant-digit radix sort of the n <= I * 1024 words in key[] (LDS) by their bits [lo_bit, lo_bit + bits), ascending and
+// stable, by the whole 1024-thread workgroup.  Four bits a pass.  Thread t holds the I consecutive words t * I .. (those below n):
+// it counts its words per digit in a register of sixteen nibbles (a word's rank among the thread's own words of that digit is the
+// nibble before the increment), the counts are scanned over the workgroup -- two 16-bit fields per register, wave prefix by DPP
+// adds, wave totals through LDS, then every wave works out its own sixteen bases from the 16 x 16 totals (sixteen lanes, a row scan,
+// the results wave-uniform) --, every word goes to its place, and the threads read their next I consecutive words back.  No atomics;
+// the order of equal digits is the order of places, as a stable sort needs.  Two barriers a pass.  tbl: 16 x 1024 u16 (a thread's
+// sixteen bases, digit-major), tot: 16 x 16 u16.  All 1024 threads call it.
+#define SEED_RDX_BITS 4
+// (inlined on purpose: as a function of its own it gets key / tbl / tot as generic pointers and accesses LDS with FLAT instructions,
+// and that build now and then left two equal neighbours in a tie-free read of more than 8192 anchors -- harmless, the read then
+// went through the reference's procedure, but wrong)
+template <int I>
+__device__ __forceinline__ void seed_radix_words(uint64_t *key, const int n, const int lo_bit, const int bits, uint16_t *tbl, uint16_t *tot)
+{
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	uint64_t k[I];
+#pragma unroll
+	for (int e = 0; e < I; ++e) k[e] = t * I + e < n ? key[t * I + e] : 0;
+	const int mine = n - t * I < 0 ? 0 : n - t * I < I ? n - t * I : I;   // words this thread holds
+	for (int sh = lo_bit; sh < lo_bit + bits; sh += SEED_RDX_BITS) {
+		uint64_t cnt = 0;                                                // sixteen nibbles: this thread's words per digit (I <= 15)
+		uint32_t dg[I], lr[I];
+#pragma unroll
+		for (int e = 0; e < I; ++e) {
+			dg[e] = (uint32_t)(k[e] >> sh) & 15u;
+			lr[e] = (uint32_t)(cnt >> (4 * dg[e])) & 15u;
+			cnt += (e < mine ? 1ull : 0ull) << (4 * dg[e]);
+		}
+		uint32_t c2[8], own[8];                                          // digits 2 j (low half) and 2 j + 1 (high half)
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const uint32_t b = (uint32_t)(cnt >> (8 * j)) & 0xffu;
+			own[j] = (b & 15u) | (b >> 4) << 16;
+			uint32_t v = own[j];                                         // inclusive prefix over the wave (no field passes 13 312)
+			v += (uint32_t)dpp_or_old<DPP_ROW_SHR(1), 0xf>(0, (int)v);
+			v += (uint32_t)dpp_or_old<DPP_ROW_SHR(2), 0xf>(0, (int)v);
+			v += (uint32_t)dpp_or_old<DPP_ROW_SHR(4), 0xf>(0, (int)v);
+			v += (uint32_t)dpp_or_old<DPP_ROW_SHR(8), 0xf>(0, (int)v);
+			v += (uint32_t)dpp_or_old<DPP_ROW_BCAST15, 0xa>(0, (int)v);
+			v += (uint32_t)dpp_or_old<DPP_ROW_BCAST31, 0xc>(0, (int)v);
+			c2[j] = v;
+		}
+		if (lane == 63) {
+#pragma unroll
+			for (int j = 0; j < 8; ++j) ((uint32_t*)tot)[wave * 8 + j] = c2[j];
+		}
+		__syncthreads();
+		// lane d < 16 of every wave: words of digit d in front of this wave's, words of smaller digits in front of those
+		uint32_t bv = 0;
+		{
+			const int d = lane & 15;
+			uint32_t all = 0, before = 0;
+#pragma unroll
+			for (int x = 0; x < 16; ++x) { const uint32_t v = tot[x * 16 + d]; all += v; before += x < wave ? v : 0u; }
+			uint32_t inc = all;                                          // words of digits <= d: prefix over the sixteen lanes of the row
+			inc += (uint32_t)dpp_or_old<DPP_ROW_SHR(1), 0xf>(0, (int)inc);
+			inc += (uint32_t)dpp_or_old<DPP_ROW_SHR(2), 0xf>(0, (int)inc);
+			inc += (uint32_t)dpp_or_old<DPP_ROW_SHR(4), 0xf>(0, (int)inc);
+			inc += (uint32_t)dpp_or_old<DPP_ROW_SHR(8), 0xf>(0, (int)inc);
+			bv = inc - all + before;
+		}
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const uint32_t bj = (uint32_t)__builtin_amdgcn_readlane((int)bv, 2 * j) | (uint32_t)__builtin_amdgcn_readlane((int)bv, 2 * j + 1) << 16;
+			const uint32_t v = c2[j] - own[j] + bj;                      // exclusive over the workgroup, both fields at once
+			tbl[(2 * j) * SEED_TPB_C + t] = (uint16_t)v;
+			tbl[(2 * j + 1) * SEED_TPB_C + t] = (uint16_t)(v >> 16);
+		}
+		// (a thread reads its own sixteen entries back: LDS operations of one wave are performed in order)
+#ifdef SEED_EXP_BARRIER2
+		__syncthreads();
+#endif
+#pragma unroll
+		for (int e = 0; e < I; ++e) if (e < mine) key[tbl[dg[e] * SEED_TPB_C + t] + lr[e]] = k[e];
+		__syncthreads();
+		if (sh + SEED_RDX_BITS < lo_bit + bits) {
+#pragma unroll
+			for (int e = 0; e < I; ++e) if (e < mine) k[e] = key[t * I + e];
+		}
+	}
+}
+
 // takes the reads (and work items) of up to max_n2 anchors: sixteen waves with bucket tables up to max_n anchors, four
 // above (the LDS layout is chosen per read; the launch reserves the larger of the two)
 #define SEED_TPB 1024
@@ -471,12 +555,19 @@ __device__ __forceinline__ void seed_isort(uint64_t *key, uint16_t *idx, int beg
 __host__ __device__ inline int seed_table_waves(int workers) { return workers >= 32 ? SEED_TPB / 64 : 4; }
 __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max_n, int max_n2, int try_network, const int64_t *__restrict__ off,
                                                   const ulonglong2 *__restrict__ src, ulonglong2 *__restrict__ a,
-                                                  const SeedItem *__restrict__ items, const unsigned long long *__restrict__ n_items)
+                                                  const SeedItem *__restrict__ items, const unsigned long long *__restrict__ n_items,
+                                                  int phase, uint32_t *__restrict__ tied, unsigned long long *__restrict__ n_tied)
 {
+	// phase 0: every unit start to end.  phase 1: the network only -- a unit with equal x is put on the list `tied` instead of going
+	// through the reference's procedure here; phase 2: that procedure for the units on the list.  A read with equal x takes ~1 ms
+	// (serial digit walks), a tie-free one ~60 us: in one launch the few tied reads are the kernel's tail with the rest of the chip
+	// idle; as a launch of their own they leave the chip to whatever the process' other streams have to run.
 	extern __shared__ uint64_t seed_lds[];
 	const int lane = threadIdx.x;
-	const int64_t n_units = n_reads + (int64_t)*n_items;               // whole reads, then the buckets k_seed_sort_huge left
-	for (int64_t r = blockIdx.x; r < n_units; r += gridDim.x) {
+	const int64_t n_units = phase == 2 ? (int64_t)*n_tied : n_reads + (int64_t)*n_items;   // whole reads, then the buckets k_seed_sort_huge left
+	if (phase == 2) try_network = 0;
+	for (int64_t r0 = blockIdx.x; r0 < n_units; r0 += gridDim.x) {
+		const int64_t r = phase == 2 ? (int64_t)tied[r0] : r0;
 		int64_t b, n64;
 		int shift0 = 56;
 		if (r < n_reads) { b = off[r]; n64 = off[r + 1] - b; }
@@ -504,7 +595,145 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 		// reference's procedure below (whose top levels are serial walks over thousands of digits).
 		int pow2 = 64;
 		while (pow2 < n) pow2 <<= 1;
+		// First attempt: key and place packed into one 64-bit word -- strand, reference id and position in as many bits as the read's
+		// largest id and position need, 14 bits of place below them; the order of the words is the order of x, the place only separates
+		// equal x, which sends the read to the reference's procedure anyway -- and the words sorted by a radix sort over the key bits
+		// (seed_radix_words: ~24 key bits for an 8 kb read against a few hundred references, i.e. six passes) or, for the reads beyond
+		// max_n, by a bitonic network on neighbouring PAIRS of words (ds_read_b128 / ds_write_b128: both partners of two adjacent
+		// comparators are adjacent in LDS, ascending, or descending on a merge's mirror step).  The version further below -- 64-bit key
+		// plus 16-bit place, one comparator at a time, 91 steps for 4 800 anchors -- issued eight LDS instructions per comparator and
+		// took 97-137 us per read; it remains for reads whose ids and positions do not fit 50 bits.
+		int packed_state = try_network ? 0 : 2;                           // 0: sorted and tie-free, 1: equal x found, 2: not attempted / keys too wide
+#ifdef SEED_STAMPS
+		unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SEED_T(k) stp[k] = __builtin_amdgcn_s_memtime()
+#else
+#define SEED_T(k)
+#endif
+		SEED_T(0);
 		if (try_network) {
+			typedef unsigned long long sd_u64x2 __attribute__((ext_vector_type(2)));
+			constexpr int PLACE_BITS = 14;
+			if (lane == 0) { qn[0] = 0; qn[1] = 0; qn[2] = 0; }
+			__syncthreads();
+			uint32_t or_lo = 0, or_hi = 0;
+			for (int i = lane; i < n; i += SEED_TPB) {
+#ifdef SEED_EXP_NOLOAD
+				const uint64_t x = (uint64_t)(i * 2654435761u) & 0xffffffull;     // (timing experiment)
+#else
+				const uint64_t x = src[b + i].x;
+#endif
+				key[i] = x;
+				or_lo |= (uint32_t)x; or_hi |= (uint32_t)(x >> 32) & 0x7fffffffu;
+			}
+			for (int d = 32; d; d >>= 1) { or_lo |= (uint32_t)__shfl_xor((int)or_lo, d, 64); or_hi |= (uint32_t)__shfl_xor((int)or_hi, d, 64); }
+			SEED_T(1);
+			if (wl == 0) { atomicOr((unsigned int*)&qn[1], or_lo); atomicOr((unsigned int*)&qn[2], or_hi); }
+			__syncthreads();
+			const int pbits = qn[1] ? 32 - __builtin_clz((unsigned)qn[1]) : 0, rbits = qn[2] ? 32 - __builtin_clz((unsigned)qn[2]) : 0;
+			const int kbits = 1 + rbits + pbits;                         // strand | id | position
+			if (kbits + PLACE_BITS > 64) packed_state = 2;
+			__syncthreads();
+			if (packed_state == 0) {
+				for (int i = lane; i < n; i += SEED_TPB) {
+					const uint64_t x = key[i];
+					key[i] = (((x >> 63) << (rbits + pbits)) | (((x >> 32) & 0x7fffffffull) << pbits) | (x & 0xffffffffull)) << PLACE_BITS | (uint64_t)i;
+				}
+				__syncthreads();
+			}
+			SEED_T(2);
+			const int items = (n + SEED_TPB - 1) / SEED_TPB;
+			// (the radix sort's tables lie over idx[], the bucket tables and the digit counts, all unused until the procedure below)
+			const bool radix = packed_state == 0 && items <= 13 && (size_t)cap_n * 2 + (size_t)n_tab * (1536 + 1024) >= 2 * 16 * SEED_TPB + 512;
+			if (radix) {
+				uint16_t *tbl = (uint16_t*)(key + cap_n), *tot = tbl + 16 * SEED_TPB;
+#if defined(SEED_EXP_PASSES)
+				const int rb = SEED_EXP_PASSES * SEED_RDX_BITS;                 // (timing experiment: wrong order)
+#else
+				const int rb = (kbits + SEED_RDX_BITS - 1) / SEED_RDX_BITS * SEED_RDX_BITS;
+#endif
+				switch (items) {
+				case 1: seed_radix_words<1>(key, n, PLACE_BITS, rb, tbl, tot); break;
+				case 2: seed_radix_words<2>(key, n, PLACE_BITS, rb, tbl, tot); break;
+				case 3: seed_radix_words<3>(key, n, PLACE_BITS, rb, tbl, tot); break;
+				case 4: seed_radix_words<4>(key, n, PLACE_BITS, rb, tbl, tot); break;
+				case 5: seed_radix_words<5>(key, n, PLACE_BITS, rb, tbl, tot); break;
+				case 6: seed_radix_words<6>(key, n, PLACE_BITS, rb, tbl, tot); break;
+				case 7: seed_radix_words<7>(key, n, PLACE_BITS, rb, tbl, tot); break;
+				case 8: seed_radix_words<8>(key, n, PLACE_BITS, rb, tbl, tot); break;
+				case 9: case 10: seed_radix_words<10>(key, n, PLACE_BITS, rb, tbl, tot); break;
+				default: seed_radix_words<13>(key, n, PLACE_BITS, rb, tbl, tot); break;
+				}
+			}
+			if (packed_state == 0) {
+				auto cex = [](unsigned long long &lo, unsigned long long &hi) { if (lo > hi) { const unsigned long long t = lo; lo = hi; hi = t; } };
+				for (int k = 2; k <= (radix ? 0 : pow2); k <<= 1) {
+					for (int j = k >> 1; j > 0; j >>= 1) {
+						if (j == 1) {                                             // partners are neighbours: a pair per load
+							for (int t0 = lane; 2 * t0 + 1 < n; t0 += 2 * SEED_TPB) {
+								const int t1 = t0 + SEED_TPB;
+								const bool h1 = 2 * t1 + 1 < n;
+								sd_u64x2 v0 = *(const sd_u64x2*)(key + 2 * t0), v1 = h1 ? *(const sd_u64x2*)(key + 2 * t1) : v0;
+								if (v0.x > v0.y) { const sd_u64x2 s2 = {v0.y, v0.x}; *(sd_u64x2*)(key + 2 * t0) = s2; }
+								if (h1 && v1.x > v1.y) { const sd_u64x2 s2 = {v1.y, v1.x}; *(sd_u64x2*)(key + 2 * t1) = s2; }
+							}
+						} else {
+							const bool mirror = j == k >> 1;
+							for (int d0 = lane; d0 < pow2 / 4; d0 += 2 * SEED_TPB) {  // two double comparators in flight per thread
+								int pi[2], plo[2], kind[2];                           // kind 0: nothing, 1: both comparators, 2: only the one whose partner is plo
+								unsigned long long ax[2], ay[2], bx[2], by[2];
+#pragma unroll
+								for (int u = 0; u < 2; ++u) {
+									const int t = 2 * (d0 + u * SEED_TPB);
+									pi[u] = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+									plo[u] = mirror ? ((pi[u] | (k - 1)) - (pi[u] & (j - 1))) - 1 : pi[u] | j;   // the lower of the two partners' places
+									kind[u] = (d0 + u * SEED_TPB >= pow2 / 4 || plo[u] >= n) ? 0 : plo[u] + 1 < n ? 1 : 2;
+									ax[u] = ay[u] = bx[u] = 0; by[u] = ~0ull;
+									if (kind[u] == 1) {
+										const sd_u64x2 A = *(const sd_u64x2*)(key + pi[u]), B = *(const sd_u64x2*)(key + plo[u]);
+										ax[u] = A.x; ay[u] = A.y; bx[u] = B.x; by[u] = B.y;
+									} else if (kind[u] == 2) { ax[u] = key[pi[u]]; ay[u] = key[pi[u] + 1]; bx[u] = key[plo[u]]; }   // (place plo + 1 is padding: +inf)
+								}
+#pragma unroll
+								for (int u = 0; u < 2; ++u) {
+									if (kind[u] == 0) continue;
+									const unsigned long long ax0 = ax[u], ay0 = ay[u];
+									if (mirror) { cex(ax[u], by[u]); cex(ay[u], bx[u]); }         // pi ~ plo + 1, pi + 1 ~ plo
+									else { cex(ax[u], bx[u]); cex(ay[u], by[u]); }
+									if (ax[u] == ax0 && ay[u] == ay0) continue;                   // nothing moved
+									if (kind[u] == 1) {
+										const sd_u64x2 A = {ax[u], ay[u]}, B = {bx[u], by[u]};
+										*(sd_u64x2*)(key + pi[u]) = A; *(sd_u64x2*)(key + plo[u]) = B;
+									} else { key[pi[u]] = ax[u]; key[pi[u] + 1] = ay[u]; key[plo[u]] = bx[u]; }
+								}
+							}
+						}
+						__syncthreads();
+					}
+				}
+				SEED_T(3);
+				int ties = 0;
+				for (int i = lane; i + 1 < n; i += SEED_TPB) ties |= (key[i] >> PLACE_BITS) == (key[i + 1] >> PLACE_BITS);
+				if (ties) qn[0] = 1;
+				__syncthreads();
+				packed_state = qn[0];
+				__syncthreads();
+				if (packed_state == 0) {
+					SEED_T(4);
+#ifndef SEED_EXP_NOGATHER
+					for (int i = lane; i < n; i += SEED_TPB) a[b + i] = src[b + (int)(key[i] & ((1u << PLACE_BITS) - 1u))];
+#endif
+#ifdef SEED_STAMPS
+					__syncthreads();
+					SEED_T(5);
+					if (blockIdx.x == 7 && lane == 0) printf("[seed stamp] n=%d load %llu, bits+repack %llu, sort %llu, ties %llu, gather %llu (ticks of 10 ns)\n", n, stp[1] - stp[0], stp[2] - stp[1], stp[3] - stp[2], stp[4] - stp[3], stp[5] - stp[4]);
+#endif
+					continue;
+				}
+				if (phase == 1) { if (lane == 0) tied[atomicAdd(n_tied, 1ull)] = (uint32_t)r; continue; }
+			}
+		}
+		if (packed_state == 2 && try_network) {
 			// bitonic network in its all-ascending form (first step of a merge compares mirror positions), so that the
 			// virtual +inf padding behind the n real keys never has to move and needs no storage
 			for (int i = lane; i < n; i += SEED_TPB) { key[i] = src[b + i].x; idx[i] = (uint16_t)i; }
@@ -545,6 +774,7 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 				for (int i = lane; i < n; i += SEED_TPB) a[b + i] = src[b + idx[i]];
 				continue;
 			}
+			if (phase == 1) { if (lane == 0) tied[atomicAdd(n_tied, 1ull)] = (uint32_t)r; continue; }
 		}
 		for (int i = lane; i < n; i += SEED_TPB) { key[i] = src[b + i].x; idx[i] = (uint16_t)i; }
 		if (lane == 0) { qbase[0] = SeedRange{0, (uint16_t)n, (uint16_t)shift0, 0}; qn[0] = 1; qn[1] = 0; qn[2] = 0; qn[3] = 0; }
@@ -712,6 +942,9 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 			__syncthreads();
 		}
 		for (int i = lane; i < n; i += SEED_TPB) a[b + i] = src[b + idx[i]];
+#ifdef SEED_STAMPS
+		if (phase == 2 && lane == 0) printf("[seed stamp] phase 2 unit %lld of %lld: n=%d, %llu ticks\n", (long long)r0, (long long)n_units, n, (unsigned long long)(__builtin_amdgcn_s_memtime() - stp[0]));
+#endif
 	}
 }
 
@@ -755,7 +988,7 @@ hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag
 		const int huge_max = cap <= 0 ? 0 : (int)(huge_max64 < 0x7fffffff ? huge_max64 : 0x7fffffff);
 		SeedItem *items = (SeedItem*)sc.stacks;
 		unsigned long long *n_items = sc.totals + 2;
-		hipError_t e = hipMemsetAsync(n_items, 0, 8, st);
+		hipError_t e = hipMemsetAsync(n_items, 0, 16, st);                  // (and the count of tied units behind it)
 		if (e != hipSuccess) return e;
 		if (cap > 0 && total > cap) {
 			const unsigned hgrid = (unsigned)(n_reads < 256 ? n_reads : 256);
@@ -763,12 +996,20 @@ hipError_t launch_seed_expand_sort(hipStream_t st, const SeedIndex &ix, int flag
 			                   d_off, (ulonglong2*)d_unsorted, (ulonglong2*)d_a, items, n_items);
 		}
 		const int64_t units = n_reads + (total > cap && cap > 0 ? total / 65 : 0);
-		const unsigned grid = (unsigned)(units < 256 * 8 ? units : 256 * 8);
+		static const int grid_cap = getenv("CHAINDP_SEED_GRID") ? atoi(getenv("CHAINDP_SEED_GRID")) : 256 * 8;   // (read once; tuning only)
+		const unsigned grid = (unsigned)(units < grid_cap ? units : grid_cap);
 		static const int try_network = getenv("CHAINDP_SEED_FORCE_EXACT") == nullptr;      // measurement switch: every read through the reference's procedure
 		if (cap > 0) {
 			size_t lds = seed_sort_lds_bytes(max_n, 32, 8);
 			if (max_n2 > max_n && seed_sort_lds_bytes(max_n2, 4, 2) > lds) lds = seed_sort_lds_bytes(max_n2, 4, 2);
-			hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(SEED_TPB), lds, st, n_reads, max_n, max_n2, try_network, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a, items, n_items);
+			if (try_network && sc.tied) {
+				hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(SEED_TPB), lds, st, n_reads, max_n, max_n2, 1, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a, items, n_items,
+				                   1, sc.tied, sc.totals + 3);
+				hipLaunchKernelGGL(k_seed_sort, dim3(grid < 256 ? grid : 256), dim3(SEED_TPB), lds, st, n_reads, max_n, max_n2, 0, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a, items, n_items,
+				                   2, sc.tied, sc.totals + 3);
+			} else
+				hipLaunchKernelGGL(k_seed_sort, dim3(grid), dim3(SEED_TPB), lds, st, n_reads, max_n, max_n2, try_network, d_off, (const ulonglong2*)d_unsorted, (ulonglong2*)d_a, items, n_items,
+				                   0, (uint32_t*)nullptr, sc.totals + 3);
 		}
 		// reads beyond SEED_HUGE_STACK x cap anchors: one thread each in global memory
 		hipLaunchKernelGGL(k_seed_sort_big, dim3((unsigned)((n_reads + 63) / 64)), dim3(64), 0, st, n_reads, huge_max, d_off, (const ulonglong2*)d_unsorted,
