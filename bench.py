@@ -124,6 +124,7 @@ def main():
     kms = dev.kernel_ms(reset=True)
     dev.set_profiling(False)
     stats = dev.stats()
+    handed_over = {"to_one_unit_per_wave_kernel": dev.leftover_units(), "to_dense_kernel": dev.deep_units()}   # this rank's last timed step
 
     # max over ranks of the timed region; sum of anchors
     elapsed_max, total_all = shard.reduce_job(elapsed, total, dist if world > 1 else None,
@@ -185,7 +186,7 @@ def main():
                 "limited_by": "VALU instruction issue (see issue)", "issue": measured_issue(total, dp_ms),
             },
             "kernel_ms": {"prepass": pre_ms, "chain_dp": dp_ms, "compact": cmp_ms},
-            "handed_over": {"to_one_unit_per_wave_kernel": dev.leftover_units(), "to_dense_kernel": dev.deep_units()},   # rank 0's last step
+            "handed_over": handed_over,
             "host": {"generate_s": t_gen, "upload_s": t_up, "upload_GBps": total * 16 / t_up / 1e9 if t_up > 0 else None},
         }
         out.update(extras)
@@ -470,6 +471,7 @@ def measure_extras(torch, chaindp, dev, par, off, anchors, total):
         ex["end_to_end_pipelined"] = {"error": repr(e)}
     # the host half (mm_chain_dp_bottom, chain.c:329-431) on the GPU as well, timed on its own
     try:
+        dev.backtrack(par, 3)                                        # first use: allocations (they would sit inside the event window)
         dev.set_profiling(True); dev.kernel_ms(reset=True)
         t0 = time.perf_counter()
         coff, u, boff, b = dev.backtrack(par, 3)

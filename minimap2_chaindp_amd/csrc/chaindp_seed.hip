@@ -535,9 +535,6 @@ __device__ __forceinline__ void seed_radix_words(uint64_t *key, const int n, con
 			tbl[(2 * j + 1) * SEED_TPB_C + t] = (uint16_t)(v >> 16);
 		}
 		// (a thread reads its own sixteen entries back: LDS operations of one wave are performed in order)
-#ifdef SEED_EXP_BARRIER2
-		__syncthreads();
-#endif
 #pragma unroll
 		for (int e = 0; e < I; ++e) if (e < mine) key[tbl[dg[e] * SEED_TPB_C + t] + lr[e]] = k[e];
 		__syncthreads();

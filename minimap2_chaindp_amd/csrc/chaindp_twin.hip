@@ -362,10 +362,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 
 			// ---- the unit goes on?
 			bool goes_on = cnt_prev == TW_TILE && c_tile0 + TW_TILE < c_room;
-#ifndef TW_SLOW_ROOM
-#define TW_SLOW_ROOM 0
-#endif
-			if (goes_on && ((slow_h * 8 > c_tile0 + TW_TILE && c_room - (c_tile0 + TW_TILE) > TW_SLOW_ROOM) || g.force_left == 2)) {
+			if (goes_on && (slow_h * 8 > c_tile0 + TW_TILE || g.force_left == 2)) {
 				// a unit that keeps needing second chunks (more than one anchor in eight) is cheaper in k_chain_units: hand the rest of
 				// it over.  The tiles up to the one flushed below are done: k_chain_units goes on behind them (the count rides in the
 				// high word of the start; force_left == 2 is the tests' way to send every unit down this road)
