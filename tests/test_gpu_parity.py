@@ -351,6 +351,54 @@ def test_run_is_idempotent_and_staged_api(dev):
     assert st["anchors"] == int(off[-1]) and st["reads"] == 50 and st["units"] > 0
 
 
+@pytest.mark.parametrize("min_sc", [40, 10], ids=["singletons_dropped", "singletons_emitted"])
+def test_compaction_works_from_the_singleton_masks(dev, min_sc):
+    """The prepass only MARKS singletons (anchors with nothing in reach on either side); their f, p, v and flag byte are written on
+    demand (chaindp_download, chaindp_run_device).  Compaction straight after the run -- those arrays still holding another batch's
+    values at the singletons' places -- must give the reference's new_seed[], with min_sc above q_span (no singleton is emitted) and
+    below it (every singleton is, chain.c:304); the download afterwards must give the reference's f, p, v."""
+    dev.set_ring(128); dev.set_variant(0)
+    stale_off, stale_a = ag.generate("map-ont", n_reads=30, seed=5)
+    dev.chain_batch(P.preset("map-ont"), stale_off, stale_a)
+    dev.compact(P.preset("map-ont"))
+    par = P.preset("ava-ont", min_sc=min_sc)
+    off, a = ag.generate("ava-ont", n_reads=60, seed=99)
+    dev.upload(off, a)
+    dev.run(par)
+    soff, seeds = dev.compact(par)
+    of, op, ov, _ = ol.oracle_batch(par, off, a, threads=8)
+    assert int(soff[-1]) == len(seeds)
+    n_single_records = 0
+    for r in range(len(off) - 1):
+        lo, hi = int(off[r]), int(off[r + 1])
+        exp = ol.oracle_compact(par, np.ascontiguousarray(a[lo:hi]), of[lo:hi].copy(), op[lo:hi].copy(), ov[lo:hi].copy())
+        assert seeds[int(soff[r]):int(soff[r + 1])].tobytes() == exp.tobytes(), (min_sc, r)
+    single = (op < 0) & (ov == of) & (of == ((a[:, 1] >> np.uint64(32)) & np.uint64(0xff)).astype(np.int32))
+    assert single.sum() > 100                                           # the batch has them
+    n_single_records = int((single & (ov >= min_sc)).sum())
+    assert (n_single_records > 0) == (min_sc <= 15)
+    f, p, v = dev.download()
+    assert np.array_equal(f, of) and np.array_equal(p, op) and np.array_equal(v, ov)
+
+
+def test_run_on_the_callers_device_arrays(dev):
+    """chaindp_run_device: offsets, anchors and the three result arrays are the caller's own HBM allocations (torch tensors here);
+    the results, singletons included, are complete when the stream has drained."""
+    import torch
+    dev.set_ring(128); dev.set_variant(0)
+    par = P.preset("ava-ont")
+    off, a = ag.generate("ava-ont", n_reads=40, seed=31)
+    n = int(off[-1])
+    t_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    t_a = torch.from_numpy(a.view(np.int64).copy()).cuda()
+    t_f, t_p, t_v = (torch.full((n,), 0x5a5a5a5a, dtype=torch.int32, device="cuda") for _ in range(3))
+    torch.cuda.synchronize()
+    dev.run_device(par, len(off) - 1, n, t_off.data_ptr(), t_a.data_ptr(), None, t_f.data_ptr(), t_p.data_ptr(), t_v.data_ptr())
+    dev.sync()
+    of, op, ov, _ = ol.oracle_batch(par, off, a, threads=8)
+    assert np.array_equal(t_f.cpu().numpy(), of) and np.array_equal(t_p.cpu().numpy(), op) and np.array_equal(t_v.cpu().numpy(), ov)
+
+
 def test_reference_anchor_dumps_chain_like_the_oracle(dev):
     """Real-read dumps (oracle/mt_dump.c: the reference's own front half on its test/*.fa) through
     the GPU, with each read's own DP arguments."""
