@@ -382,21 +382,42 @@ def test_compaction_works_from_the_singleton_masks(dev, min_sc):
 
 
 def test_run_on_the_callers_device_arrays(dev):
-    """chaindp_run_device: offsets, anchors and the three result arrays are the caller's own HBM allocations (torch tensors here);
+    """chaindp_run_device: offsets, anchors and the three result arrays are the caller's own HBM allocations (plain hipMalloc here);
     the results, singletons included, are complete when the stream has drained."""
-    import torch
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    H2D, D2H = 1, 2
+
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), max(nbytes, 16)) == 0
+        return p
+
     dev.set_ring(128); dev.set_variant(0)
     par = P.preset("ava-ont")
     off, a = ag.generate("ava-ont", n_reads=40, seed=31)
+    off = np.ascontiguousarray(off, np.int64); a = np.ascontiguousarray(a, np.uint64)
     n = int(off[-1])
-    t_off = torch.from_numpy(off.astype(np.int64)).cuda()
-    t_a = torch.from_numpy(a.view(np.int64).copy()).cuda()
-    t_f, t_p, t_v = (torch.full((n,), 0x5a5a5a5a, dtype=torch.int32, device="cuda") for _ in range(3))
-    torch.cuda.synchronize()
-    dev.run_device(par, len(off) - 1, n, t_off.data_ptr(), t_a.data_ptr(), None, t_f.data_ptr(), t_p.data_ptr(), t_v.data_ptr())
-    dev.sync()
+    d_off, d_a = dmalloc(off.nbytes), dmalloc(a.nbytes)
+    d_res = [dmalloc(4 * n) for _ in range(3)]
+    try:
+        assert hip.hipMemcpy(d_off, off.ctypes.data, off.nbytes, H2D) == 0 and hip.hipMemcpy(d_a, a.ctypes.data, a.nbytes, H2D) == 0
+        for d in d_res:
+            assert hip.hipMemset(d, 0x5a, 4 * n) == 0
+        dev.run_device(par, len(off) - 1, n, d_off.value, d_a.value, None, d_res[0].value, d_res[1].value, d_res[2].value)
+        dev.sync()
+        got = [np.empty(n, np.int32) for _ in range(3)]
+        for g, d in zip(got, d_res):
+            assert hip.hipMemcpy(g.ctypes.data, d, 4 * n, D2H) == 0
+    finally:
+        for d in [d_off, d_a] + d_res:
+            hip.hipFree(d)
     of, op, ov, _ = ol.oracle_batch(par, off, a, threads=8)
-    assert np.array_equal(t_f.cpu().numpy(), of) and np.array_equal(t_p.cpu().numpy(), op) and np.array_equal(t_v.cpu().numpy(), ov)
+    assert np.array_equal(got[0], of) and np.array_equal(got[1], op) and np.array_equal(got[2], ov)
 
 
 def test_reference_anchor_dumps_chain_like_the_oracle(dev):
