@@ -254,7 +254,7 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		es.n = 3;
 	}
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[0], st));
-	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, ctx->d_unit_aux, d_n_segs));
+	HIP_TRY(ctx, chaindp::launch_prepass(st, q, n_reads, total, d_off, d_a, ctx->d_sumq, ctx->d_units, ctx->d_counters, ctx->pre, ctx->d_unit_aux, d_n_segs, ctx->d_left_cnt));
 	if (ctx->prof) HIP_TRY(ctx, hipEventRecord(es.e[1], st));
 	// per-read gap-cost table for the fast variant (skipped when the table would not apply)
 	uint16_t *lut = nullptr;
@@ -276,7 +276,7 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 		HIP_TRY(ctx, hipMemsetAsync(ctx->d_tg, 0, (size_t)ctx->cap_anchors * 8, st));
 		ctx->epoch = 1;
 	}
-	HIP_TRY(ctx, hipMemsetAsync(ctx->d_left_cnt, 0, 4 * sizeof(unsigned long long), st));
+	// (d_left_cnt -- hand-over counts and the twin kernel's queue word -- was zeroed by the prepass' first kernel)
 	Unit *const deep = ctx->deep_handover ? ctx->d_deep : nullptr;
 	unsigned int *const deep_cnt = (unsigned int*)(ctx->d_left_cnt + 1);
 	if (ctx->variant == 0 && lut) {

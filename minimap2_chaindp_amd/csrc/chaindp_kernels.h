@@ -48,7 +48,8 @@ size_t prepass_scratch_bytes(int64_t max_anchors, size_t *mask_bytes, size_t *bl
 // counters[0] = units emitted (low 32 bits) | singleton anchors resolved by the prepass (high 32 bits)
 hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off, const void *d_a,
                           unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
-                          UnitAux *d_unit_aux = nullptr, const int32_t *d_n_segs = nullptr);
+                          UnitAux *d_unit_aux = nullptr, const int32_t *d_n_segs = nullptr,
+                          unsigned long long *d_left_cnt = nullptr);   // d_left_cnt: four hand-over words, zeroed with the batch's other accumulators
 // f, p, v, flags[] of the batch's singletons (the prepass only marks them; the compaction reads the marks)
 hipError_t launch_fill_singles(hipStream_t st, const Params &par, int64_t total, const void *d_a, PrepassScratch sc,
                                int32_t *d_f, int32_t *d_p, int32_t *d_v, uint8_t *d_flags);

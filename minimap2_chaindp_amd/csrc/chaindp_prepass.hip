@@ -40,8 +40,18 @@ __device__ __forceinline__ int64_t read_of(const int64_t *__restrict__ off, int6
 // Reads that the first and the last anchor of every 1024-anchor block belong to.  The anchor-parallel kernels
 // of the prepass and of the compaction all cut the batch into the same blocks; a per-block binary search by one
 // thread (28 dependent loads before the block can start) was most of their run time.
-__global__ __launch_bounds__(256) void k_block_reads(int64_t n_reads, int64_t total, const int64_t *__restrict__ off, int2 *__restrict__ block_reads)
+__global__ __launch_bounds__(256) void k_block_reads(int64_t n_reads, int64_t total, const int64_t *__restrict__ off, int2 *__restrict__ block_reads,
+                                                    unsigned long long *__restrict__ sumq, unsigned long long *__restrict__ counters,
+                                                    unsigned int *__restrict__ hist, unsigned long long *__restrict__ left_cnt)
 {
+	// the batch's accumulators start at zero: done here, by the first kernel of the step, instead of four memsets of a few bytes
+	// to a few hundred kilobytes (~25 us each on the stream: 0.1 ms of a 4 ms step)
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += (int64_t)gridDim.x * blockDim.x) sumq[i] = 0;
+	if (blockIdx.x == 0) {
+		if (threadIdx.x < 2) counters[threadIdx.x] = 0;
+		if (threadIdx.x < 4 && left_cnt) left_cnt[threadIdx.x] = 0;
+		for (int i = threadIdx.x; i < 2 * 128; i += blockDim.x) hist[i] = 0;      // (2 x UNIT_CLASSES: class counts, cursors)
+	}
 	const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int64_t g0 = b * PRE_PER_BLOCK;
 	if (g0 >= total) return;
@@ -409,18 +419,20 @@ __global__ __launch_bounds__(256) void k_build_lut(Params par, int64_t n_reads, 
 
 hipError_t launch_prepass(hipStream_t st, const Params &par, int64_t n_reads, int64_t total, const int64_t *d_off, const void *d_a,
                           unsigned long long *d_sumq, Unit *d_units, unsigned long long *d_counters, PrepassScratch sc,
-                          UnitAux *d_unit_aux, const int32_t *d_n_segs)
+                          UnitAux *d_unit_aux, const int32_t *d_n_segs, unsigned long long *d_left_cnt)
 {
-	hipError_t e = hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st);
-	if (e != hipSuccess || n_reads <= 0 || total <= 0) return e;
-	if ((e = hipMemsetAsync(d_sumq, 0, (size_t)n_reads * sizeof(unsigned long long), st)) != hipSuccess) return e;
+	hipError_t e = hipSuccess;
+	if (n_reads <= 0 || total <= 0) {                                // an empty batch: no units, no singletons, nothing handed over
+		if ((e = hipMemsetAsync(d_counters, 0, 2 * sizeof(unsigned long long), st)) != hipSuccess) return e;
+		return d_left_cnt ? hipMemsetAsync(d_left_cnt, 0, 4 * sizeof(unsigned long long), st) : hipSuccess;
+	}
 	const int64_t blocks = (total + PRE_PER_BLOCK - 1) / PRE_PER_BLOCK;
 	const int64_t words = (total + 63) / 64;
-	hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, st, n_reads, total, d_off, sc.block_reads);
+	hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, st, n_reads, total, d_off, sc.block_reads,
+	                   d_sumq, d_counters, sc.hist, d_left_cnt);
 	hipLaunchKernelGGL(k_prepass, dim3((unsigned)((blocks + PRE_BLOCK / 64 - 1) / (PRE_BLOCK / 64))), dim3(PRE_BLOCK), 0, st, par, n_reads, total, d_off, (const ulonglong2*)d_a,
 	                   d_sumq, sc.start_mask, sc.single_mask, sc.emit_mask, sc.block_cnt, sc.block_reads);
 	if ((e = launch_scan_u64(st, blocks, sc.block_cnt, sc.tile_tmp, d_counters)) != hipSuccess) return e;
-	if ((e = hipMemsetAsync(sc.hist, 0, 2 * UNIT_CLASSES * sizeof(unsigned int), st)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_emit_units, dim3((unsigned)((words + 255) / 256 < 2048 ? (words + 255) / 256 : 2048)), dim3(256), 0, st, n_reads, words, d_off,
 	                   sc.start_mask, sc.block_cnt, sc.units_tmp, sc.hist, sc.block_reads);
 	hipLaunchKernelGGL(k_unit_bases, dim3(1), dim3(64), 0, st, sc.hist, sc.hist + UNIT_CLASSES, d_unit_aux ? sc.key_range : nullptr);

@@ -615,11 +615,7 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 			__syncthreads();
 			uint32_t or_lo = 0, or_hi = 0;
 			for (int i = lane; i < n; i += SEED_TPB) {
-#ifdef SEED_EXP_NOLOAD
-				const uint64_t x = (uint64_t)(i * 2654435761u) & 0xffffffull;     // (timing experiment)
-#else
 				const uint64_t x = src[b + i].x;
-#endif
 				key[i] = x;
 				or_lo |= (uint32_t)x; or_hi |= (uint32_t)(x >> 32) & 0x7fffffffu;
 			}
@@ -717,9 +713,7 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 				__syncthreads();
 				if (packed_state == 0) {
 					SEED_T(4);
-#ifndef SEED_EXP_NOGATHER
 					for (int i = lane; i < n; i += SEED_TPB) a[b + i] = src[b + (int)(key[i] & ((1u << PLACE_BITS) - 1u))];
-#endif
 #ifdef SEED_STAMPS
 					__syncthreads();
 					SEED_T(5);
