@@ -346,11 +346,11 @@ class Device:
 
     def set_deep_handover(self, on=True):
         """Test hook: False keeps every unit in the launch that took it (k_chain_units then serves long scans from HBM/L2); 2 hands
-        over any unit with a few deep scans, whatever its length, to k_chain_dense, 3 to k_chain_dense1 (small test inputs reach
-        either kernel)."""
+        over any unit with a few deep scans, whatever its length, to k_chain_dense, 3 to k_chain_dense1, 4 to k_chain_dense16 (small
+        test inputs reach every kernel)."""
         self._lib.chaindp_debug_set_deep_handover.restype = C.c_int
         self._lib.chaindp_debug_set_deep_handover.argtypes = [C.c_void_p, C.c_int]
-        self._check(self._lib.chaindp_debug_set_deep_handover(self._ctx, on if on in (2, 3) else int(bool(on))))
+        self._check(self._lib.chaindp_debug_set_deep_handover(self._ctx, on if on in (2, 3, 4) else int(bool(on))))
 
     def stats(self):
         st = (C.c_int64 * 4)()

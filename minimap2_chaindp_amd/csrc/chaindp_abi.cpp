@@ -305,6 +305,8 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 	if (deep && lut) {
 		HIP_TRY(ctx, chaindp::launch_chain_dense(st, q, total / 64 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,
 		                                         d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_route));
+		HIP_TRY(ctx, chaindp::launch_chain_dense16(st, q, total / 64 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,
+		                                           d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_route));
 		HIP_TRY(ctx, chaindp::launch_chain_dense1(st, q, total / 64 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,
 		                                          ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_route, (unsigned int*)(ctx->d_left_cnt + 2), d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags));
 	}
@@ -665,14 +667,14 @@ extern "C" int chaindp_debug_set_twin_handover(chaindp_ctx_t *ctx, int mode)
 
 // test hook (not in the public header): 0 keeps every unit in the launch that took it (the deep path of the small rings stays
 // covered by the parity tests), 1 (default) hands long units whose scans keep reaching past the ring to k_chain_dense or, when the
-// batch is dense all over, k_chain_dense1; 2 any unit with a few such scans, to k_chain_dense; 3 the same to k_chain_dense1 (small
-// test inputs reach either kernel)
+// batch is dense all over, k_chain_dense1; 2 any unit with a few such scans, to k_chain_dense; 3 the same to k_chain_dense1; 4 the same
+// to k_chain_dense16 (small test inputs reach every kernel)
 extern "C" int chaindp_debug_set_deep_handover(chaindp_ctx_t *ctx, int on)
 {
 	if (!ctx) return CHAINDP_ERR_ARG;
 	ctx->deep_handover = on != 0;
 	ctx->deep_eager = on >= 2;
-	ctx->deep_route = on == 2 ? 1 : on == 3 ? 2 : 0;
+	ctx->deep_route = on == 2 ? 1 : on == 3 ? 2 : on == 4 ? 3 : 0;
 	return CHAINDP_OK;
 }
 

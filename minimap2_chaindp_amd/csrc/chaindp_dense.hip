@@ -34,13 +34,26 @@
 #include "chaindp_wave.h"
 #include "chaindp_fast.h"
 
+// This file is compiled twice (csrc/Makefile): as it is -- k_chain_dense, eight waves per unit, rounds of 512 predecessors, the ring
+// of CHAINDP_DENSE_RING anchors -- and with -DDN_VARIANT16 -- k_chain_dense16 in a namespace of its own, SIXTEEN waves per unit, rounds
+// of 1024 predecessors and a ring as long: for a batch whose tail is at most a workgroup per CU of long units (256), where a unit's
+// time is the number of rounds its scans take and most of the chip would otherwise idle (6 % on 200 units; slower from 500 on).  The device decides
+// which of the two finds work (dense_wide(), chaindp_fast.h), as it does between them and k_chain_dense1.
 namespace chaindp {
-
+#ifdef DN_VARIANT16
+namespace dense16 {
+#define DN_RING 1024
+#define DN_WAVES 16
+#define DN_ROUND 16
+#define DN_LAUNCH launch_chain_dense16
+#define DN_WIDE 1
+#else
 #define DN_RING CHAINDP_DENSE_RING
-#ifndef DN_WAVES
 #define DN_WAVES 8                      // waves per unit
-#endif
 #define DN_ROUND 8                      // chunks per round
+#define DN_LAUNCH launch_chain_dense
+#define DN_WIDE 0
+#endif
 #define DN_CPW (DN_ROUND / DN_WAVES)    // chunks a wave evaluates per round
 static_assert(DN_CPW * DN_WAVES == DN_ROUND && DN_WAVES >= 2, "the waves must tile the round");
 static_assert(64 * DN_ROUND == DN_RING, "the first round is the ring");
@@ -50,7 +63,7 @@ typedef FastLds<DN_RING> DnL;
 // atomics of one instruction on ONE address take a turn each); what the waves tell each other about a round's chunks, twice (a
 // round uses the half of its parity, so that a wave may start the next round while another still reads this one's): the
 // chunk's scores per lane, its maximum, its summary; the read's table of 1 - cost (int16)
-#define DN_BM 12288u
+#define DN_BM (DnL::V_OFF + 4u * DN_RING)  // 12 288 for the ring of 512
 #define DN_BM_BYTES (CHAINDP_DENSE_BITCAP / 8u)
 #define DN_SINK (DN_BM + DN_BM_BYTES)
 #define DN_SC (DN_SINK + 4u * 64u * DN_WAVES)
@@ -172,6 +185,7 @@ __device__ __forceinline__ int dn_scan8_max(int v)
 	v = max(v, dpp_or_old<DPP_ROW_SHR(1), 0xf>(INT_MIN, v));
 	v = max(v, dpp_or_old<DPP_ROW_SHR(2), 0xf>(INT_MIN, v));
 	v = max(v, dpp_or_old<DPP_ROW_SHR(4), 0xf>(INT_MIN, v));
+	if (DN_ROUND > 8) v = max(v, dpp_or_old<DPP_ROW_SHR(8), 0xf>(INT_MIN, v));   // (sixteen chunks: still one row of lanes)
 	return v;
 }
 
@@ -314,7 +328,8 @@ __device__ __forceinline__ void run_unit_dense(const UnitCtx &c, int64_t room, i
 						int la, lb;
 						if (sh == 1) { la = dpp_or_old<DPP_ROW_SHR(1), 0xf>(0, ca); lb = dpp_or_old<DPP_ROW_SHR(1), 0xf>(DN_NEG, cb); }
 						else if (sh == 2) { la = dpp_or_old<DPP_ROW_SHR(2), 0xf>(0, ca); lb = dpp_or_old<DPP_ROW_SHR(2), 0xf>(DN_NEG, cb); }
-						else { la = dpp_or_old<DPP_ROW_SHR(4), 0xf>(0, ca); lb = dpp_or_old<DPP_ROW_SHR(4), 0xf>(DN_NEG, cb); }
+						else if (sh == 4) { la = dpp_or_old<DPP_ROW_SHR(4), 0xf>(0, ca); lb = dpp_or_old<DPP_ROW_SHR(4), 0xf>(DN_NEG, cb); }
+						else { la = dpp_or_old<DPP_ROW_SHR(8), 0xf>(0, ca); lb = dpp_or_old<DPP_ROW_SHR(8), 0xf>(DN_NEG, cb); }
 						cb = max(lb + ca, cb); ca = la + ca;
 					}
 					const int x_out = max(n_skip + ca, cb);                             // n_skip behind chunk `lane`
@@ -376,6 +391,7 @@ template <bool SAMEGAP>
 __global__ __launch_bounds__(64 * DN_WAVES) void k_chain_dense(DenseArgs g)
 {
 	if (dense_all(g.long_units, g.route)) return;                   // a batch that is dense all over: k_chain_dense1 has the units
+	if (dense_wide(g.count, g.long_units, g.route, g.par.max_dist_x) != (DN_WIDE != 0)) return;   // a short tail: sixteen waves per unit (the other build of this file)
 	UnitCtx c;
 	c.a = g.a; c.f = g.f; c.p = g.p; c.v = g.v; c.tg = nullptr; c.tg_hi = 0; c.first_child = g.first_child; c.flags = g.flags; c.min_sc = g.par.min_sc;
 	c.s_w = nullptr; c.s_t = nullptr; c.s_v = nullptr; c.s_xhi = nullptr; c.s_yhi = nullptr; c.s_lut = nullptr; c.s_dummy = nullptr;
@@ -405,12 +421,17 @@ __global__ __launch_bounds__(64 * DN_WAVES) void k_chain_dense(DenseArgs g)
 	}
 }
 
-size_t dense_lds_bytes(int lut_stride) { return (size_t)DN_LUT + (size_t)lut_stride * 2; }
+static size_t dense_lds_bytes(int lut_stride) { return (size_t)DN_LUT + (size_t)lut_stride * 2; }
 
-hipError_t launch_chain_dense(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
-                              const uint16_t *d_lut, int lut_stride, const Unit *d_deep, const unsigned long long *d_deep_cnt,
-                              int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags,
-                              const unsigned int *d_long_units, int deep_route)
+#ifdef DN_VARIANT16
+}  // namespace dense16
+using namespace dense16;
+#endif
+
+hipError_t DN_LAUNCH(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
+                     const uint16_t *d_lut, int lut_stride, const Unit *d_deep, const unsigned long long *d_deep_cnt,
+                     int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags,
+                     const unsigned int *d_long_units, int deep_route)
 {
 	if (max_units <= 0 || !d_lut) return hipSuccess;
 	const size_t lds = dense_lds_bytes(lut_stride);

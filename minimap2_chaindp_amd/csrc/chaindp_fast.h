@@ -48,10 +48,22 @@ struct UnitCtx {
 // least every second anchor so far and the unit may have this many anchors left: the unit starts over there, and a short unit
 // or one with the odd deep scan (ordinary ava-ont batches have a handful) would only become a tail of its own behind the launch
 // true: the batch is dense all over (k_chain_dense1 takes the handed-over units), false: it has a tail (k_chain_dense does).
-// route: 0 decides by the number of long units in the batch, 1 / 2 force the one or the other (tests)
+// route: 0 decides by the number of long units in the batch, 1 / 2 / 3 force k_chain_dense / k_chain_dense1 / k_chain_dense16 (tests)
 __device__ __forceinline__ bool dense_all(const unsigned int *long_units, int route)
 {
 	return route == 2 || (route == 0 && long_units && *long_units > CHAINDP_DENSE_MAX_LONG);
+}
+
+// true: the handed-over units go to the sixteen-waves-per-unit build of k_chain_dense (rounds of 1024 predecessors): the batch's
+// tail is at most one workgroup per CU of them, and 32-bit differences stay exact over a ring of 1024 anchors.  route 3 forces it.
+// (Measured, tools/dense_probe.py: 200 units of 15-38 k anchors 107 -> 101 ms; 500 units 127 -> 179 ms: rounds are fewer, 1.3
+// instead of 2 per anchor, but each costs sixteen waves' barriers, so it only pays while the chip is not full.)
+#define CHAINDP_DENSE16_MAX_UNITS 256u
+__device__ __forceinline__ bool dense_wide(const unsigned long long *count, const unsigned int *long_units, int route, int max_dist_x)
+{
+	if (route) return route == 3;
+	return !dense_all(long_units, route) && (uint32_t)*count <= CHAINDP_DENSE16_MAX_UNITS &&
+	       ((uint64_t)(int64_t)max_dist_x + 1) * 1025ull < (1ull << 32);
 }
 
 #ifndef CHAINDP_DEEP_HANDOVER

@@ -68,7 +68,7 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
                         const Unit *d_units_all = nullptr, const unsigned long long *d_counters_all = nullptr,
                         Unit *d_deep = nullptr, unsigned int *d_deep_cnt = nullptr, const unsigned int *d_long_units = nullptr,
                         int deep_eager = 0,    // tests: hand over any unit with a few deep scans
-                        int deep_route = 0);   // 0: the batch decides which dense kernel runs; 1: k_chain_dense; 2: k_chain_dense1 (tests)
+                        int deep_route = 0);   // 0: the batch decides which dense kernel runs; 1: k_chain_dense; 2: k_chain_dense1; 3: k_chain_dense16 (tests)
 // *d_long_units: units of CHAINDP_LONG_UNIT anchors and more in the batch (PrepassScratch::hist + CHAINDP_LONG_UNIT_CLASS, valid
 // after launch_prepass); above CHAINDP_DENSE_MAX_LONG of them nothing is handed over
 #define CHAINDP_LONG_UNIT_CLASS 65      // hist[c] after k_unit_bases = units in length classes above c; class 65 ends at 8191 anchors
@@ -81,6 +81,11 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
 #define CHAINDP_DENSE_RING 512
 #define CHAINDP_DENSE_UNITS 2048u      // units handed over per batch (about two rounds of workgroups on the chip)
 hipError_t launch_chain_dense(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
+                              const uint16_t *d_lut, int lut_stride, const Unit *d_deep, const unsigned long long *d_deep_cnt,
+                              int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags,
+                              const unsigned int *d_long_units, int deep_route);
+// the same with sixteen waves per unit (chaindp_dense.hip built with -DDN_VARIANT16): the device sends a short tail there
+hipError_t launch_chain_dense16(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
                               const uint16_t *d_lut, int lut_stride, const Unit *d_deep, const unsigned long long *d_deep_cnt,
                               int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags,
                               const unsigned int *d_long_units, int deep_route);

@@ -205,13 +205,13 @@ def test_large_bw_takes_the_general_path(dev):
     dict(max_skip=-1, max_dist_y=700),
 ])
 @pytest.mark.parametrize("gen,n_reads", [("dense", 2), ("ties", 40)])
-@pytest.mark.parametrize("ring,handover", [(128, False), (512, False), (128, 2), (256, 2), (128, 3)])
+@pytest.mark.parametrize("ring,handover", [(128, False), (512, False), (128, 2), (256, 2), (128, 3), (128, 4)])
 def test_fast_variant_parameter_corners(dev, par_over, gen, n_reads, ring, handover):
     """The table-driven variant folds the window, gap and bandwidth tests of chain.c:252-260 into one unsigned compare and keeps
     marks by distance; 'dense' walks the whole window (ring chunks, far marks, the deep path), 'ties' breaks early.  Without the
     handover k_chain_units serves the long scans of the dense units from HBM/L2 to the end; with it they are redone by
-    k_chain_dense (eight waves per unit, marks as bits by distance in LDS; mode 2) or k_chain_dense1 (one wave per unit, the same
-    marks; mode 3)."""
+    k_chain_dense (eight waves per unit, marks as bits by distance in LDS; mode 2), k_chain_dense1 (one wave per unit, the same
+    marks; mode 3) or k_chain_dense16 (sixteen waves per unit, rounds of 1024 predecessors; mode 4)."""
     dev.set_ring(ring)
     dev.set_variant(False)
     dev.set_deep_handover(handover)
@@ -231,12 +231,13 @@ def test_fast_variant_parameter_corners(dev, par_over, gen, n_reads, ring, hando
         dev.set_ring(128)
 
 
-@pytest.mark.parametrize("mode", [True, 3], ids=["as_the_batch_decides", "one_wave_per_unit"])
+@pytest.mark.parametrize("mode", [True, 2, 3, 4], ids=["as_the_batch_decides", "eight_waves_per_unit", "one_wave_per_unit", "sixteen_waves_per_unit"])
 @pytest.mark.parametrize("gen_kw", [dict(read_len=3000, n_hits=12), dict(read_len=4000, n_hits=20), dict(read_len=6000, n_hits=6)])
 def test_dense_units_are_redone_by_the_dense_kernel(dev, gen_kw, mode):
-    """Default settings: units whose scans keep reaching past the LDS ring (dense repeats) are handed by k_chain_units to
-    k_chain_dense (a batch this small has a tail: eight waves per unit), which redoes them from scratch -- same f/p/v and
-    new_seed[] as the oracle; mode 3 sends them to k_chain_dense1 instead, the kernel of batches that are dense all over."""
+    """Default settings: units whose scans keep reaching past the LDS ring (dense repeats) are handed by k_chain_units to one of the
+    dense kernels, which redoes them from scratch -- same f/p/v and new_seed[] as the oracle.  A batch this small has a short tail:
+    sixteen waves per unit (k_chain_dense16); mode 2 sends the units to k_chain_dense (eight waves: the kernel of a longer tail),
+    mode 3 to k_chain_dense1 (one wave: batches that are dense all over), mode 4 to k_chain_dense16 whatever the batch looks like."""
     dev.set_ring(128)
     dev.set_deep_handover(mode)
     par = P.preset("ava-ont")

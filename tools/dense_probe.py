@@ -14,7 +14,7 @@ for n_reads in [int(x) for x in sys.argv[1:]] or [100]:
     total = int(off[-1])
     with chaindp.Device(0, max_anchors=total + 1, max_reads=n_reads + 1) as dev:
         dev.upload(off, a)
-        cases = (("k_chain_units alone", 128, False), ("handover, as the batch decides", 128, True), ("handover to k_chain_dense", 128, 2), ("handover to k_chain_dense1", 128, 3))
+        cases = (("k_chain_units alone", 128, False), ("handover, as the batch decides", 128, True), ("handover to k_chain_dense", 128, 2), ("handover to k_chain_dense1", 128, 3), ("handover to k_chain_dense16", 128, 4))
         if os.environ.get("CHAINDP_LIB"):
             cases = cases[1:2]
         for label, ring, handover in cases:
