@@ -587,19 +587,20 @@ __global__ __launch_bounds__(SEED_TPB) void k_seed_sort(int64_t n_reads, int max
 		uint8_t *lab = (uint8_t*)(qn + 4);                                 // cap_n: the current digit of every position
 		ulonglong2 *ag = a + b;                                            // this read's output range doubles as scratch until the final gather
 		__syncthreads();
-		// A sorted order is unique when all keys differ, and then any sort will do: try a bitonic network first (the whole
-		// workgroup busy) and keep its result unless two neighbours are equal; only reads with equal x go through the
-		// reference's procedure below (whose top levels are serial walks over thousands of digits).
+		// A sorted order is unique when all keys differ, and then any sort will do: sort first (the whole workgroup busy) and keep
+		// the result unless two neighbours are equal; only reads with equal x go through the reference's procedure below (whose
+		// top levels are serial walks over thousands of digits).
 		int pow2 = 64;
 		while (pow2 < n) pow2 <<= 1;
 		// First attempt: key and place packed into one 64-bit word -- strand, reference id and position in as many bits as the read's
 		// largest id and position need, 14 bits of place below them; the order of the words is the order of x, the place only separates
 		// equal x, which sends the read to the reference's procedure anyway -- and the words sorted by a radix sort over the key bits
-		// (seed_radix_words: ~24 key bits for an 8 kb read against a few hundred references, i.e. six passes) or, for the reads beyond
-		// max_n, by a bitonic network on neighbouring PAIRS of words (ds_read_b128 / ds_write_b128: both partners of two adjacent
-		// comparators are adjacent in LDS, ascending, or descending on a merge's mirror step).  The version further below -- 64-bit key
-		// plus 16-bit place, one comparator at a time, 91 steps for 4 800 anchors -- issued eight LDS instructions per comparator and
-		// took 97-137 us per read; it remains for reads whose ids and positions do not fit 50 bits.
+		// (seed_radix_words: ~24 key bits for an 8 kb read against a few hundred references, i.e. six passes of ~3 us) or, where the
+		// LDS behind the keys has no room for its tables (other LDS sizes than this device's), by a bitonic network on neighbouring
+		// PAIRS of words (ds_read_b128 / ds_write_b128: both partners of two adjacent comparators are adjacent in LDS, ascending, or
+		// descending on a merge's mirror step).  The version further below -- 64-bit key plus 16-bit place, one comparator at a time,
+		// 91 steps for 4 800 anchors -- issued eight LDS instructions per comparator and took 97-137 us per read; it remains for
+		// reads whose ids and positions do not fit 50 bits.
 		int packed_state = try_network ? 0 : 2;                           // 0: sorted and tie-free, 1: equal x found, 2: not attempted / keys too wide
 #ifdef SEED_STAMPS
 		unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
