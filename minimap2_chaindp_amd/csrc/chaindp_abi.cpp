@@ -64,6 +64,7 @@ struct chaindp_ctx {
 	bool use_lut = true;
 	// compaction (allocated on first use)
 	int32_t *d_first_child = nullptr;
+	unsigned int *d_twin_queue = nullptr;   // k_chain_twin's eight grab counters, a cache line apart (2 KB)
 	int64_t *d_seeds_off = nullptr;
 	void *d_seeds = nullptr;
 	// seed collection (allocated on first use, grown with the batch)
@@ -141,7 +142,7 @@ extern "C" void chaindp_destroy(chaindp_ctx_t *ctx)
 	if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	for (auto &es : ctx->pending) for (int k = 0; k < es.n; ++k) (void)hipEventDestroy(es.e[k]);
-	void *bufs[] = {ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_sumq, ctx->d_units,
+	void *bufs[] = {ctx->d_twin_queue, ctx->d_off, ctx->d_a, ctx->d_n_segs, ctx->d_f, ctx->d_p, ctx->d_v, ctx->d_tg, ctx->d_sumq, ctx->d_units,
 	                ctx->d_counters, ctx->d_unit_aux, ctx->d_left, ctx->d_left_cnt, ctx->d_deep, ctx->pre.start_mask, ctx->pre.single_mask, ctx->pre.emit_mask, ctx->pre.block_cnt, ctx->pre.tile_tmp, ctx->pre.units_tmp, ctx->pre.hist, ctx->pre.block_reads, ctx->d_lut, ctx->d_ptrs, ctx->cmp.flags, ctx->cmp.block_cnt, ctx->cmp.tile_tmp, ctx->cmp.n_seeds, ctx->cmp.sub, ctx->d_first_child, ctx->d_seeds_off, ctx->d_seeds};
 	for (void *b : bufs) if (b) (void)hipFree(b);
 	for (void *b : ctx->bot_allocs) if (b) (void)hipFree(b);
@@ -171,6 +172,7 @@ extern "C" chaindp_ctx_t *chaindp_create(int device, int64_t max_anchors, int64_
 	if (e == hipSuccess) e = hipMalloc(&ctx->d_a, na * 16);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_n_segs, nr * 4);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_f, na * 4);
+	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_twin_queue, 8 * 64 * sizeof(unsigned int));
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_p, na * 4);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_v, na * 4);
 	if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_tg, na * 8);
@@ -292,7 +294,7 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 			                                        (unsigned int*)ctx->d_left_cnt + 1, route, ctx->twin_force_left, total));
 		HIP_TRY(ctx, chaindp::launch_chain_twin(st, qt, total / 2, d_off, d_a, ctx->d_sumq, lut, lut_stride, ctx->d_units, ctx->d_counters,
 		                                        d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->d_left, (unsigned int*)ctx->d_left_cnt,
-		                                        ctx->twin_force_left, total, ctx->d_unit_aux, route));
+		                                        ctx->twin_force_left, total, ctx->d_unit_aux, route, ctx->d_twin_queue));
 		const int64_t left_grid = total / 2 < 32768 ? total / 2 : 32768;
 		HIP_TRY(ctx, chaindp::launch_chain(st, ctx->ring, q, left_grid, d_off, d_a, d_n_segs, ctx->d_sumq, lut, lut_stride, ctx->d_left,
 		                                   ctx->d_left_cnt, d_f, d_p, d_v, ctx->d_tg, ctx->epoch, ctx->d_first_child, ctx->cmp.flags,

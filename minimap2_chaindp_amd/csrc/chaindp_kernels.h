@@ -102,7 +102,7 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
                              const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride, const Unit *d_units,
                              const unsigned long long *d_counters, int32_t *d_f, int32_t *d_p, int32_t *d_v,
                              int32_t *d_first_child, uint8_t *d_flags, Unit *d_left, unsigned int *d_left_cnt, int force_left, int64_t total,
-                             const UnitAux *d_unit_aux, const unsigned int *d_route = nullptr);
+                             const UnitAux *d_unit_aux, const unsigned int *d_route = nullptr, unsigned int *d_queue = nullptr   /* 8 x 64 words: the grab counters */);
 size_t twin_lds_bytes();
 
 // Four units per wave, 16 lanes each, two predecessors per lane (chaindp_quad.hip): takes a batch of ordinary units whose reads all

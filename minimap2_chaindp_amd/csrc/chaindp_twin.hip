@@ -160,7 +160,7 @@ struct TwinArgs {
 	uint8_t *flags;
 	Unit *left;                       // leftover list for k_chain_units
 	unsigned int *left_cnt;
-	unsigned int *queue;              // next unit nobody has taken yet (the halves' first chunks are dealt statically: it starts behind them)
+	unsigned int *queue;              // eight grab counters, 64 words apart (the halves' first grabs are dealt statically: they start behind them)
 	const unsigned int *route;        // *route != 0: k_chain_quad (launched in front of this kernel) has taken the batch
 	int force_left;                   // test switch: 1 hand every unit over untouched, 2 hand every unit over after its first tile (resumed there)
 	int64_t total;                    // anchors of the batch
@@ -265,9 +265,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 	uint64_t contm = 0;                                            // halves that are in their second (= last) chunk
 	const uint32_t st_addr = TW_ST + TW_ST_HALF * (uint32_t)h;
 #define TW_COLD (*TW_LDS(TwinCold, st_addr))
+	// The unit queue.  Eight counters, a cache line apart (one same-address atomic takes ~7.5 ns: 133 M a second for the whole chip
+	// on ONE counter), workgroup b on counter b mod 8.  A half's p-th grab of its counter k is the chunk of TW_QCH units number
+	// 8 p + k while the list's long front lasts (units [0, U1)), and ONE unit -- number 8 (p - G1k) + k of [U1, n_units) -- for the
+	// last sixteen units per half: the list is longest first, every half works on units of the same length at any time, and the
+	// halves run out of work within one grab of each other -- eight units of 140 anchors were 0.4 ms, 0.2 ms of idle tail on average
+	// behind a 3 ms kernel.  (Smaller grabs all along cost more than they save: same-address atomics.)
+	const uint32_t xcd = blockIdx.x & 7u;
+	const uint32_t n_halves = 2u * gridDim.x;
+#ifndef TW_END_UNITS
+#define TW_END_UNITS 16u                // units per half that are dealt in small pieces at the end of the list
+#define TW_PIECE 1u                     // ... this many at a time (measured on the 76 M-anchor shard: 16 / 1: 2.86 ms, 16 / 2: 2.88, 24 / 1: 2.88, 32 / 2: 2.90, 8 / 2: 2.95; one counter, 8 at a time all along: 3.04)
+#endif
+	const uint32_t U1 = n_units > (long long)TW_END_UNITS * n_halves ? ((uint32_t)n_units - TW_END_UNITS * n_halves) & ~(8u * TW_QCH - 1u) : 0u;
+	const uint32_t G1k = U1 / (8u * TW_QCH);                             // grabs of whole chunks per counter
+	auto grab = [&](uint32_t p, uint32_t &nx, uint32_t &ne) {
+		if (p < G1k) { nx = (8u * p + xcd) * TW_QCH; ne = nx + TW_QCH; }
+		else { nx = U1 + TW_PIECE * (8u * (p - G1k) + xcd); ne = nx + TW_PIECE; }
+	};
 	if (hl == 0) {
-		const uint32_t nx = TW_QCH * (2u * blockIdx.x + (uint32_t)h);                   // the half's first chunk of units: dealt statically
-		tw_st64(st_addr, nx, nx + TW_QCH); tw_st64(st_addr + 8u, 0u, 0u);               // TwinCold: next (low word: next unit, high word: end of the chunk), base
+		uint32_t nx, ne;
+		grab(((blockIdx.x >> 3) << 1) | (uint32_t)h, nx, ne);                            // the half's first grab: dealt statically
+		tw_st64(st_addr, nx, ne); tw_st64(st_addr + 8u, 0u, 0u);                         // TwinCold: next (low word: next unit, high word: end of the chunk), base
 		tw_st64(st_addr + 16u, 0u, 0u); tw_st64(st_addr + 24u, 0u, 0u);                 // x_carry, rel0, room
 		tw_st64(st_addr + 32u, 0u, (uint32_t)-TW_TILE);                                 // read, tile0
 		tw_st64(st_addr + TW_CARRY, 0xfffffffcu, 0u); tw_st64(st_addr + TW_CARRY + 8u, 0u, 0u);   // carry, second chunks so far
@@ -433,11 +452,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 			while (!goes_on && live) {
 				uint32_t nx = (uint32_t)c_next, ne = (uint32_t)((uint64_t)c_next >> 32);
 				if (nx >= ne) {
-					// the chunk is used up: the next TW_QCH units nobody has taken (the list is longest first, so the two halves of a
-					// wave, and all waves, work on units of similar length at any time and run out of work together)
+					// the chunk is used up: the counter's next grab (the list is longest first, so the two halves of a wave, and all
+					// waves, work on units of similar length at any time and run out of work together)
 					uint32_t q0 = 0;
-					if (lane == 0) q0 = atomicAdd(g.queue, (unsigned int)TW_QCH);
-					nx = TW_UNI(q0); ne = nx + TW_QCH;
+					if (lane == 0) q0 = atomicAdd(g.queue + 64u * xcd, 1u);
+					grab(TW_UNI(q0), nx, ne);
 					have_rec = false;
 				}
 				if ((int64_t)nx >= n_units) {
@@ -707,7 +726,7 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
                              const unsigned long long *d_sumq, const uint16_t *d_lut, int lut_stride, const Unit *d_units,
                              const unsigned long long *d_counters, int32_t *d_f, int32_t *d_p, int32_t *d_v,
                              int32_t *d_first_child, uint8_t *d_flags, Unit *d_left, unsigned int *d_left_cnt, int force_left, int64_t total,
-                             const UnitAux *d_unit_aux, const unsigned int *d_route)
+                             const UnitAux *d_unit_aux, const unsigned int *d_route, unsigned int *d_queue)
 {
 	if (max_units <= 0) return hipSuccess;
 	if (!d_unit_aux) return hipErrorInvalidValue;
@@ -719,14 +738,16 @@ hipError_t launch_chain_twin(hipStream_t st, const Params &par, int64_t max_unit
 	const int64_t cap = (int64_t)cus * (wg_per_cu >= 1 && wg_per_cu <= 24 ? wg_per_cu : 24);
 	if (blocks > cap) blocks = cap;
 	if (blocks < 1) blocks = 1;
+	blocks = (blocks + 7) & ~(int64_t)7;                           // eight grab counters, workgroup b on counter b mod 8: the same number of halves on each
+	if (!d_queue) return hipErrorInvalidValue;
 	{
-		const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)(d_left_cnt + 1), (int)(2 * TW_QCH * blocks), 1, st);   // the queue starts behind the first chunks
+		const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)d_queue, (int)(2 * blocks / 8), 8 * 64, st);   // every counter starts behind its halves' first grabs
 		if (e != hipSuccess) return e;
 	}
 	TwinArgs g;
 	g.par = par; g.off = d_off; g.a = (const ulonglong2*)d_a; g.sumq = d_sumq; g.lut = d_lut; g.lut_stride = lut_stride;
 	g.units = d_units; g.aux = d_unit_aux; g.counters = d_counters; g.f = d_f; g.p = d_p; g.v = d_v; g.first_child = d_first_child; g.flags = d_flags;
-	g.left = d_left; g.left_cnt = d_left_cnt; g.queue = d_left_cnt + 1; g.route = d_route; g.force_left = force_left; g.total = total;
+	g.left = d_left; g.left_cnt = d_left_cnt; g.queue = d_queue; g.route = d_route; g.force_left = force_left; g.total = total;
 	// diagnostic: CHAINDP_TWIN_STAMP=1 makes the kernel stamp where its waves' time goes (s_memtime: shader-clock ticks) and this
 	// function print the averages -- it synchronises, so never set it in a timed run
 	static unsigned long long *d_stamp = nullptr;
