@@ -306,9 +306,11 @@ static int run_on_stream(chaindp_ctx *ctx, const chaindp_params_t *par, int64_t 
 	// units whose scans kept reaching past the ring (dense repeats): redone by k_chain_dense
 	if (deep && lut) {
 		HIP_TRY(ctx, chaindp::launch_chain_dense(st, q, total / 64 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,
-		                                         d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_route));
+		                                         d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_route,
+		                                           (unsigned int*)(ctx->d_left_cnt + 3) + 1));   // (the word behind the route flag: zeroed with it)
 		HIP_TRY(ctx, chaindp::launch_chain_dense16(st, q, total / 64 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,
-		                                           d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_route));
+		                                           d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags, ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_route,
+		                                           (unsigned int*)(ctx->d_left_cnt + 3) + 1));   // (the word behind the route flag: zeroed with it)
 		HIP_TRY(ctx, chaindp::launch_chain_dense1(st, q, total / 64 + 1, d_off, d_a, lut, lut_stride, ctx->d_deep, ctx->d_left_cnt + 1,
 		                                          ctx->pre.hist + CHAINDP_LONG_UNIT_CLASS, ctx->deep_route, (unsigned int*)(ctx->d_left_cnt + 2), d_f, d_p, d_v, ctx->d_first_child, ctx->cmp.flags));
 	}

@@ -89,6 +89,7 @@ struct DenseArgs {
 	int32_t *first_child;
 	uint8_t *flags;
 	const unsigned int *long_units;     // see dense_all(), chaindp_fast.h
+	unsigned int *queue;                // the next unit nobody has taken (zero when the step starts; the two builds of this kernel never both run)
 	int route;
 	unsigned long long *stamp;          // diagnostic build (-DCHAINDP_DENSE_STAMPS, run with CHAINDP_DENSE_STAMP=1): where wave 0's time goes
 };
@@ -404,7 +405,14 @@ __global__ __launch_bounds__(64 * DN_WAVES) void k_chain_dense(DenseArgs g)
 	const int tid = threadIdx.x;
 	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int64_t n_units = (int64_t)(uint32_t)g.count[0];
-	for (int64_t ub = blockIdx.x; ub < n_units; ub += gridDim.x) {
+	// units are taken from a counter, not dealt by workgroup index: they differ 2.5x in length and arrive in no order, and a batch
+	// with more units than the chip holds workgroups (2000 on 1024) otherwise ends when the unluckiest pair of them does
+	for (;;) {
+		__syncthreads();                                               // (the slot below, and the previous unit's LDS, are no longer in use)
+		if (tid == 0) lds_store_b32(DN_M, (int)atomicAdd(g.queue, 1u));
+		__syncthreads();
+		const int64_t ub = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane(lds_load_b32(DN_M));
+		if (ub >= n_units) break;
 		const Unit u = g.units[ub];
 		c.base = u.start; c.read = u.read;
 		c.rel0 = (int)(u.start - g.off[u.read]);
@@ -431,9 +439,10 @@ using namespace dense16;
 hipError_t DN_LAUNCH(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
                      const uint16_t *d_lut, int lut_stride, const Unit *d_deep, const unsigned long long *d_deep_cnt,
                      int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags,
-                     const unsigned int *d_long_units, int deep_route)
+                     const unsigned int *d_long_units, int deep_route, unsigned int *d_queue)
 {
 	if (max_units <= 0 || !d_lut) return hipSuccess;
+	if (!d_queue) return hipErrorInvalidValue;
 	const size_t lds = dense_lds_bytes(lut_stride);
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -455,7 +464,7 @@ hipError_t DN_LAUNCH(hipStream_t st, const Params &par, int64_t max_units, const
 	DenseArgs g;
 	g.par = par; g.off = d_off; g.a = (const ulonglong2*)d_a; g.lut = d_lut; g.lut_stride = lut_stride;
 	g.units = d_deep; g.count = d_deep_cnt; g.f = d_f; g.p = d_p; g.v = d_v; g.first_child = d_first_child; g.flags = d_flags;
-	g.long_units = d_long_units; g.route = deep_route;
+	g.long_units = d_long_units; g.route = deep_route; g.queue = d_queue;
 	g.stamp = nullptr;
 #ifdef CHAINDP_DENSE_STAMPS
 	static unsigned long long *d_stamp = nullptr;

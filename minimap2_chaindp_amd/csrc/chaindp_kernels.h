@@ -83,12 +83,12 @@ hipError_t launch_chain(hipStream_t st, int ring, const Params &par, int64_t max
 hipError_t launch_chain_dense(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
                               const uint16_t *d_lut, int lut_stride, const Unit *d_deep, const unsigned long long *d_deep_cnt,
                               int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags,
-                              const unsigned int *d_long_units, int deep_route);
+                              const unsigned int *d_long_units, int deep_route, unsigned int *d_queue);   // d_queue: one zeroed word (the unit counter)
 // the same with sixteen waves per unit (chaindp_dense.hip built with -DDN_VARIANT16): the device sends a short tail there
 hipError_t launch_chain_dense16(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
                               const uint16_t *d_lut, int lut_stride, const Unit *d_deep, const unsigned long long *d_deep_cnt,
                               int32_t *d_f, int32_t *d_p, int32_t *d_v, int32_t *d_first_child, uint8_t *d_flags,
-                              const unsigned int *d_long_units, int deep_route);
+                              const unsigned int *d_long_units, int deep_route, unsigned int *d_queue);   // d_queue: one zeroed word (the unit counter)
 // ... or, when the batch is dense all over, by k_chain_dense1 (chaindp_dense1.hip): one wave per unit, many per CU, the same bit
 // marks, deep chunks four at a time.  Both are launched; the device decides which one has work (dense_all(), chaindp_fast.h).
 hipError_t launch_chain_dense1(hipStream_t st, const Params &par, int64_t max_units, const int64_t *d_off, const void *d_a,
