@@ -451,6 +451,7 @@ hipError_t DN_LAUNCH(hipStream_t st, const Params &par, int64_t max_units, const
 	if (per_cu > 8) per_cu = 8;
 	if (per_cu < 1) per_cu = 1;
 	int64_t blocks = (int64_t)cus * per_cu;
+	if (DN_WIDE && blocks > (int64_t)CHAINDP_DENSE16_MAX_UNITS) blocks = CHAINDP_DENSE16_MAX_UNITS;   // (it only ever takes that many units: fewer workgroups to start and end for nothing)
 	if (blocks > max_units) blocks = max_units;
 	const void *fn = par.max_dist_y >= par.max_dist_x ? (const void*)k_chain_dense<true> : (const void*)k_chain_dense<false>;
 	{

@@ -285,37 +285,54 @@ __global__ __launch_bounds__(256) void k_emit_units(int64_t n_reads, int64_t n_w
 	// a workgroup takes many 256-word pieces and adds its class counts to the batch's once at the end: with a workgroup per piece
 	// the adds to the few classes that hold most units queued up at their addresses (37 000 workgroups on the 100k-read job,
 	// ~7.5 ns per same-address atomic: 0.3 of the kernel's 0.44 ms)
-	for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * blockDim.x) {
-	uint64_t m = start_mask[w];
-	if (m) {
-		const int64_t b = w / PRE_WORDS;
-		uint64_t pos = (uint32_t)block_base[b];             // low word: units before this block
-		for (int64_t k = b * PRE_WORDS; k < w; ++k) pos += (uint64_t)__builtin_popcountll(start_mask[k]);
-		// the read of the word's first anchor: from the block's read range (k_block_reads) instead of a search over all reads
-		// (fourteen dependent loads for 12 500 reads; a block usually lies in one read or straddles two)
-		const int2 rr = block_reads[b];
-		int64_t r = read_of(off, rr.x, rr.y, w << 6);
-		int64_t re = off[r + 1];                            // (kept across the word's units: a load per unit was a trip to L2 per unit, one after the other)
-		while (m) {
-			const int bit = __builtin_ctzll(m);
-			m &= m - 1;
-			const int64_t g = (w << 6) + bit;
-			while (g >= re) re = off[++r + 1];              // units of one word are in anchor order; reads only move forward
-			// upper bound of the unit: the next unit's start or the end of the read (singletons in between are
-			// not units, so this can overshoot the true end; the DP kernel finds the true end itself)
-			int64_t next = -1;
-			if (m) next = (w << 6) + __builtin_ctzll(m);
-			else for (int64_t k = w + 1; k < n_words && (k << 6) < re; ++k) {
-				const uint64_t mm = start_mask[k];
-				if (mm) { next = (k << 6) + __builtin_ctzll(mm); break; }
+	// A wave takes 64 consecutive mask words (four blocks: a 16-lane row each).  What a word needs from its neighbours comes out of
+	// the wave: the units in front of it inside its block from a row prefix of popcounts (it was up to fifteen loads), the start
+	// behind its last unit from the next non-empty lane (it was a walk over the following words, a load each); only a word whose
+	// next start lies beyond the wave's 64 still walks.
+	const int lane = threadIdx.x & 63;
+	for (int64_t wb = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(int64_t)63; wb < n_words; wb += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t w = wb + lane;
+		uint64_t m = w < n_words ? start_mask[w] : 0;
+		const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+		uint32_t incl = cnt;                                         // units up to this word inside its block
+		incl += (uint32_t)dpp_or_old<DPP_ROW_SHR(1), 0xf>(0, (int)incl);
+		incl += (uint32_t)dpp_or_old<DPP_ROW_SHR(2), 0xf>(0, (int)incl);
+		incl += (uint32_t)dpp_or_old<DPP_ROW_SHR(4), 0xf>(0, (int)incl);
+		incl += (uint32_t)dpp_or_old<DPP_ROW_SHR(8), 0xf>(0, (int)incl);
+		const uint64_t nz = __builtin_amdgcn_ballot_w64(m != 0);
+		const uint64_t above = lane < 63 ? nz & (~0ull << (lane + 1)) : 0ull;
+		const int nl = above ? __builtin_ctzll(above) : lane;        // the next lane that has a unit start
+		const int first_there = __shfl(m ? __builtin_ctzll(m) : 0, nl, 64);
+		const int64_t next_in_wave = above ? ((wb + nl) << 6) + first_there : -1;
+		if (m) {
+			const int64_t b = w / PRE_WORDS;
+			uint64_t pos = (uint32_t)block_base[b] + (incl - cnt);   // low word of block_base: units before this block
+			// the read of the word's first anchor: from the block's read range (k_block_reads) instead of a search over all reads
+			// (fourteen dependent loads for 12 500 reads; a block usually lies in one read or straddles two)
+			const int2 rr = block_reads[b];
+			int64_t r = read_of(off, rr.x, rr.y, w << 6);
+			int64_t re = off[r + 1];                                 // (kept across the word's units: a load per unit was a trip to L2 per unit, one after the other)
+			while (m) {
+				const int bit = __builtin_ctzll(m);
+				m &= m - 1;
+				const int64_t g = (w << 6) + bit;
+				while (g >= re) re = off[++r + 1];                   // units of one word are in anchor order; reads only move forward
+				// upper bound of the unit: the next unit's start or the end of the read (singletons in between are
+				// not units, so this can overshoot the true end; the DP kernel finds the true end itself)
+				int64_t next = -1;
+				if (m) next = (w << 6) + __builtin_ctzll(m);
+				else if (next_in_wave >= 0) next = next_in_wave;
+				else for (int64_t k = wb + 64; k < n_words && (k << 6) < re; ++k) {
+					const uint64_t mm = start_mask[k];
+					if (mm) { next = (k << 6) + __builtin_ctzll(mm); break; }
+				}
+				const int64_t end = next >= 0 && next < re ? next : re;
+				Unit u;
+				u.start = g; u.read = (int32_t)r; u.len = (int32_t)(end - g);
+				units[pos++] = u;
+				atomicAdd(&s_hist[unit_class(u.len)], 1u);
 			}
-			const int64_t end = next >= 0 && next < re ? next : re;
-			Unit u;
-			u.start = g; u.read = (int32_t)r; u.len = (int32_t)(end - g);
-			units[pos++] = u;
-			atomicAdd(&s_hist[unit_class(u.len)], 1u);
 		}
-	}
 	}
 	__syncthreads();
 	if (threadIdx.x < UNIT_CLASSES && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
