@@ -68,12 +68,14 @@ __global__ __launch_bounds__(256) void k_block_reads(int64_t n_reads, int64_t to
 // and the q_span sum are wave-uniform state carried from tile to tile, read boundaries inside a tile included (lane ranges, no
 // per-lane search): no LDS, no barrier, one 128-byte store of the block's sixteen start masks, one atomic per block and read.
 //
-// The tile loads of a full block are issued and awaited by hand.  The compiler counts the conditional stores of the singletons
-// into its bookkeeping of outstanding vector memory operations and ends up waiting for ALL of them (s_waitcnt vmcnt(0)) before every
-// tile, i.e. for the load it has just issued: one tile in flight per wave, 3.9 TB/s.  Loads return in order, so waiting until at
-// most (tile loads issued after the one needed) operations are outstanding is safe whatever stores sit between them.
+// The tile loads of a full block are issued and awaited by hand: loads return in order, so waiting until at most (tile loads issued
+// after the one needed) operations are outstanding is safe whatever else -- the atomics of a read's q_span sum -- sits between them,
+// whereas the compiler, which counts every conditional memory operation into its bookkeeping, ends up at s_waitcnt vmcnt(0) before
+// every tile, i.e. waiting for the load it has just issued.  (Between four and ten tiles in flight the kernel's time does not move.)
 #define PW_TILES (PRE_PER_BLOCK / 64)
+#ifndef PW_DEPTH
 #define PW_DEPTH 6                                                   // tiles requested ahead of the one in hand
+#endif
 
 typedef uint32_t pw_u32x4 __attribute__((ext_vector_type(4)));       // an anchor: x.lo, x.hi, y.lo, y.hi
 
