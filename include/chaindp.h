@@ -70,7 +70,9 @@ int chaindp_chain_batch(chaindp_ctx_t *ctx, const chaindp_params_t *par, int64_t
 
 /* The same in stages, so that a caller can keep a batch resident in HBM and time or
  * repeat the device stage alone.  upload/download are synchronous; run is asynchronous
- * on the context's stream until chaindp_sync(). */
+ * on the context's stream until chaindp_sync().  (An anchor with nothing in reach on either side -- f = v = q_span, p = -1,
+ * chain.c:251,283 with an empty window -- is only marked by the run; chaindp_download writes those entries before it copies, the
+ * compaction works from the marks.  chaindp_run_device, which leaves the results in the caller's own arrays, writes them itself.) */
 int chaindp_upload(chaindp_ctx_t *ctx, int64_t n_reads, const int64_t *off, const chaindp_anchor_t *a,
                    const int32_t *n_segs_per_read);
 int chaindp_run(chaindp_ctx_t *ctx, const chaindp_params_t *par);
